@@ -1,0 +1,169 @@
+/* yolo4hip.h -- C ABI of libyolo4hip.so: the MI355X (gfx950) YOLOv4 inference hot path.
+ *
+ * The reference (taipingeric/yolo-v4-tf.keras) has no FFI: its hot path is the tf.keras graph executed by
+ * `Model.predict` (reference models.py:113,159,514).  This ABI is the seam a host binds instead of
+ * TensorFlow; each entry point cites the reference code it stands in for.  See INTEGRATION.md for the
+ * ctypes binding that `yolo-v4-tf.keras_amd/yolo4hip/ext.py` uses.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative Y4_E* code; `y4_last_error()` gives the text
+ *     (thread-local).  Nothing throws, nothing aborts.
+ *   - all `*_dev` / workspace pointers are DEVICE pointers owned by the caller (the Python host owns them
+ *     as torch-ROCm tensors).  A handle never allocates device memory: scratch comes out of the bound
+ *     workspace.  (Only the standalone y4_conv2d lazily allocates one 256-byte zero page per process.)
+ *   - every launch goes on the caller's `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *     Calls are asynchronous; the caller synchronises.
+ *   - activations are NHWC.  Images are float32 [n, H, W, 3] in [0,1] (what `Yolov4.preprocess_img`
+ *     produces, reference models.py:95-98, after Keras' cast to float32).
+ *   - one handle per process/GPU; a handle is not re-entrant.
+ */
+#ifndef YOLO4HIP_H
+#define YOLO4HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Y4_OK 0
+#define Y4_EINVAL (-22)      /* bad argument / unsupported shape */
+#define Y4_ENOMEM (-12)      /* bound workspace too small */
+#define Y4_ESTATE (-1)       /* call order (workspace not bound, weights not packed) */
+#define Y4_EHIP (-5)         /* a HIP runtime call failed */
+
+#define Y4_F32 0
+#define Y4_BF16 1
+#define Y4_F16 2
+
+#define Y4_ACT_LINEAR 0
+#define Y4_ACT_LEAKY 1       /* LeakyReLU(alpha=0.1), reference custom_layers.py:29-30 */
+#define Y4_ACT_MISH 2        /* x*tanh(softplus(x)),  reference custom_layers.py:6-7  */
+
+typedef struct y4_ctx* y4_handle;
+
+/* Mirrors what `Yolov4.__init__` reads from `yolo_config` (reference models.py:26-37, config.py:1-17). */
+typedef struct y4_config {
+    int32_t img_size;          /* square input side, multiple of 32 (reference models.py:23-24) */
+    int32_t num_classes;       /* len(class_names) (reference models.py:25,27) */
+    int32_t max_batch;         /* largest n any call will pass */
+    int32_t dtype;             /* Y4_F32 | Y4_BF16 | Y4_F16: storage/MFMA-input type; accumulation is fp32 */
+    float anchors[18];         /* 3 scales x 3 anchors x (w,h) px at input resolution (config.py:4, models.py:29) */
+    float xyscale[3];          /* config.py:6 */
+    int32_t strides[3];        /* config.py:5 */
+    float iou_threshold;       /* config.py:15 */
+    float score_threshold;     /* config.py:16 */
+    int32_t max_per_class;     /* 100: custom_layers.py:293 */
+    int32_t max_total;         /* 100: custom_layers.py:294 */
+} y4_config;
+
+/* One row of the 110-conv plan, as built by the C++ runtime. */
+typedef struct y4_layer_desc {
+    int32_t idx, ksize, stride, cin, cout, act, has_bn, in_side, out_side;
+    int64_t weight_offset;     /* float offset of this layer's record in the Darknet stream (bn/bias first) */
+} y4_layer_desc;
+
+const char* y4_last_error(void);
+const char* y4_version(void);
+
+/* Replaces Yolov4.__init__ -> build_model (inference half), reference models.py:18-52,67-73: builds the
+ * 110-conv CSPDarknet53+SPP+PANet plan, the decode and the NMS stages for this config.  Host-only. */
+int y4_create(const y4_config* cfg, y4_handle* out);
+int y4_destroy(y4_handle h);
+
+int y4_num_layers(y4_handle h);
+int y4_layer_info(y4_handle h, int idx, y4_layer_desc* out);
+/* per image: conv FLOPs (2*k*k*cin*cout*ho*wo summed), decoded boxes, padded channel count of a raw head */
+int y4_model_info(y4_handle h, int64_t* flops_per_image, int32_t* num_boxes, int32_t* head_cstride,
+                  int64_t* weight_floats);
+
+/* Device memory the caller must provide: `act` = activations + decode/NMS scratch for max_batch images,
+ * `wts` = packed weights (+ per-channel scale/shift). */
+int y4_workspace_bytes(y4_handle h, size_t* act_bytes, size_t* wts_bytes);
+int y4_bind_workspace(y4_handle h, void* act_dev, size_t act_bytes, void* wts_dev, size_t wts_bytes);
+
+/* Replaces utils.load_weights (reference utils.py:12-53) + Keras set_weights: `darknet_floats_dev` is the
+ * float32 stream of a Darknet .weights file after its 20-byte header, already on the device: for conv
+ * 0..109, [beta,gamma,mean,var] x cout (or cout biases for convs 93/101/109), then cout*cin*k*k weights in
+ * (out,in,h,w) order.  Computes scale = gamma*rsqrt(var+1e-3), shift = beta-mean*scale (Keras BN eps) and
+ * re-lays every kernel as [cout_pad][kh][kw][cin] in the handle's dtype inside the bound `wts` workspace. */
+int y4_pack_weights(y4_handle h, const float* darknet_floats_dev, size_t n_floats, void* stream);
+/* Multi-GPU: after rank 0 packed and the caller broadcast the whole `wts` workspace (RCCL), the other
+ * ranks mark their copy as valid. */
+int y4_adopt_packed_weights(y4_handle h);
+
+/* Replaces yolo_model.predict(imgs) (reference models.py:50-52,514; graph custom_layers.py:100-198).
+ * Raw heads stay inside the workspace (padded to head_cstride channels). */
+int y4_forward(y4_handle h, const float* imgs_nhwc_dev, int n, void* stream);
+/* Dense float32 copies of the three raw heads, [n,g,g,3*(C+5)] each, as Keras returns them. */
+int y4_get_heads(y4_handle h, int n, float* out_s_dev, float* out_m_dev, float* out_l_dev, void* stream);
+/* Inverse of y4_get_heads: load dense float32 raw heads [n,g,g,3*(C+5)] into the workspace, so that
+ * y4_decode_nms can be driven with arbitrary logits (decode/NMS known-answer tests; reference
+ * predict_nonms feeds yolov4_head/nms with precomputed heads the same way, models.py:521-523). */
+int y4_set_heads(y4_handle h, int n, const float* in_s_dev, const float* in_m_dev, const float* in_l_dev,
+                 void* stream);
+/* Debug/parity tap: dense float32 NHWC copy of conv `idx`'s output tensor (post BN/activation/residual;
+ * for convs that write a concat slice, that slice). */
+int y4_get_conv_output(y4_handle h, int conv_idx, int n, float* out_dev, size_t out_floats, void* stream);
+
+/* Replaces yolov4_head/get_boxes + nms (reference custom_layers.py:201-298, i.e.
+ * tf.image.combined_non_max_suppression) on the heads left by y4_forward.
+ * boxes [n,max_total,4] (x1,y1,x2,y2 / img_size, clipped to [0,1], zero padded), scores [n,max_total],
+ * classes [n,max_total] (class id as float), valid [n] int32, kept_idx [n,max_total] int32 (box index
+ * n = scale_offset + (row*g+col)*3 + anchor, -1 padded; may be NULL).  iou/score thresholds < 0 mean
+ * "use the config's" (predict_nonms passes its own, reference models.py:516-523). */
+int y4_decode_nms(y4_handle h, int n, float iou_threshold, float score_threshold, float* boxes_dev,
+                  float* scores_dev, float* classes_dev, int32_t* valid_dev, int32_t* kept_idx_dev,
+                  void* stream);
+/* Replaces inference_model.predict(imgs) (reference models.py:69-73,113,159) = forward + decode + NMS. */
+int y4_predict(y4_handle h, const float* imgs_nhwc_dev, int n, float* boxes_dev, float* scores_dev,
+               float* classes_dev, int32_t* valid_dev, int32_t* kept_idx_dev, void* stream);
+
+/* Per-op device time of one forward (+decode+NMS) in ms, measured with HIP events on `stream`
+ * (synchronises).  `names` receives op names ('c17', 'spp', 'decode', 'nms', ...), 16 bytes each. */
+int y4_profile(y4_handle h, const float* imgs_nhwc_dev, int n, float* op_ms, char* names, int cap,
+               int* n_ops, void* stream);
+
+/* ---- standalone operators (same kernels as the plan uses; for unit tests and other hosts) ---- */
+
+typedef struct y4_conv_desc {
+    int32_t dtype;                 /* Y4_* of in/weights/out/res */
+    int32_t n, h, w, cin;          /* input NHWC view: [n,h,w,in_cstride][..., in_coff:in_coff+cin] */
+    int32_t cout, ksize, stride;   /* ksize 1|3; stride 1 ('same') | 2 (pad top/left 1, 'valid') */
+    int32_t act;                   /* Y4_ACT_* */
+    int32_t upsample;              /* 1: write each output pixel to its 2x2 nearest-upsampled block */
+    int32_t out_f32;               /* 1: output buffer is float32 regardless of dtype */
+    int32_t in_cstride, in_coff;
+    int32_t out_cstride, out_coff;
+    int32_t res_cstride, res_coff; /* residual view (same spatial dims as the output), used if res != NULL */
+    const void* in;
+    const void* wt;                /* packed by y4_pack_conv_weights */
+    const float* scale;            /* [cout_pad] */
+    const float* shift;            /* [cout_pad] */
+    const void* res;
+    void* out;
+    int32_t tile;                  /* 0 = auto; otherwise a tile-config id (see y4_conv_tile_count) */
+} y4_conv_desc;
+
+/* cout_pad (rows of the packed matrix) and bytes needed for a packed kernel */
+int y4_packed_conv_bytes(int dtype, int cout, int cin, int ksize, int32_t* cout_pad, size_t* bytes);
+/* Darknet (cout,cin,k,k) float32 on device -> packed [cout_pad][k][k][cin] dtype; rows >= cout are zero */
+int y4_pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw_dev, void* packed_dev,
+                         void* stream);
+/* One conv() unit of the reference (custom_layers.py:5-31) + optional Add (custom_layers.py:44) +
+ * optional UpSampling2D (custom_layers.py:147,159) + concat-slice store (custom_layers.py:68,...). */
+int y4_conv2d(const y4_conv_desc* d, void* stream);
+int y4_conv_tile_count(void);
+/* Stem conv (cin = 3): float32 images -> dtype, weights float32 [cout][3][3][3] (darknet order) */
+int y4_stem_conv(int dtype, const float* imgs_dev, int n, int h, int w, const float* w_oihw_dev,
+                 const float* scale, const float* shift, int cout, int act, void* out_dev, int out_cstride,
+                 int out_coff, void* stream);
+/* SPP (custom_layers.py:130-134): x = buf[..., 3c:4c] -> buf[..., 0:c]=maxpool13, [c:2c]=maxpool9,
+ * [2c:3c]=maxpool5 (stride 1, 'same'), buf is [n,side,side,4c] */
+int y4_spp(int dtype, void* buf_dev, int n, int side, int c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO4HIP_H */

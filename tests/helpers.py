@@ -1,0 +1,88 @@
+"""Shared test helpers (host side only; the oracle is imported by the tests themselves)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_DIR = os.path.join(ROOT, "yolo-v4-tf.keras_amd")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CLASS_DIR = os.path.join(PKG_DIR, "class_names")
+
+
+def bf16_round(x):
+    """float32 -> nearest-even bfloat16 -> float32 (what the HIP path stores)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
+def quantize(x, dtype):
+    if dtype == "f32":
+        return np.ascontiguousarray(x, dtype=np.float32)
+    if dtype == "bf16":
+        return bf16_round(x)
+    return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+def torch_dtype(dtype):
+    import torch
+    return {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dtype]
+
+
+def run_conv_gpu(x, cw, k, stride, act, dtype, residual=None, upsample=False, out_f32=False, tile=0,
+                 in_pad=(0, 0), out_pad=(0, 0)):
+    """Run y4_conv2d on NHWC float32 numpy `x` (already representable in `dtype`).
+    in_pad/out_pad = (channels before, channels after) of extra garbage around the view, to exercise
+    channel-slice reads/stores.  Returns float32 NHWC output (the slice only) and the full out buffer."""
+    import torch
+    from yolo4hip import ext
+    lib = ext.load()
+    dev = "cuda:0"
+    td = torch_dtype(dtype)
+    did = ext.DTYPE_IDS[dtype]
+    n, h, w, cin = x.shape
+    cout = cw.w.shape[0]
+    ho, wo = h // stride, w // stride
+    oh, ow = (2 * ho, 2 * wo) if upsample else (ho, wo)
+    in_cs = in_pad[0] + cin + in_pad[1]
+    xin = torch.full((n, h, w, in_cs), 7.0, dtype=td, device=dev)
+    xin[..., in_pad[0]:in_pad[0] + cin] = torch.from_numpy(x).to(dev).to(td)
+    cstore = (cout + 7) // 8 * 8
+    out_cs = out_pad[0] + cstore + out_pad[1]
+    otd = torch.float32 if out_f32 else td
+    out = torch.full((n, oh, ow, out_cs), -5.0, dtype=otd, device=dev)
+    cpad, nbytes = C.c_int32(), C.c_size_t()
+    ext.check(lib.y4_packed_conv_bytes(did, cout, cin, k, C.byref(cpad), C.byref(nbytes)))
+    packed = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    w_dev = torch.from_numpy(np.ascontiguousarray(cw.w)).to(dev)
+    ext.check(lib.y4_pack_conv_weights(did, cout, cin, k, ext.ptr(w_dev), ext.ptr(packed), ext.stream_ptr()))
+    scale, shift = cw.scale_shift()
+    sc = torch.zeros(cpad.value, dtype=torch.float32, device=dev); sc[:cout] = torch.from_numpy(scale).to(dev)
+    sh = torch.zeros(cpad.value, dtype=torch.float32, device=dev); sh[:cout] = torch.from_numpy(shift).to(dev)
+    d = ext.y4_conv_desc()
+    d.dtype = did; d.n, d.h, d.w, d.cin = n, h, w, cin
+    d.cout, d.ksize, d.stride, d.act = cout, k, stride, {"mish": 2, "leaky": 1, None: 0}[act]
+    d.upsample, d.out_f32 = int(upsample), int(out_f32)
+    d.in_cstride, d.in_coff = in_cs, in_pad[0]
+    d.out_cstride, d.out_coff = out_cs, out_pad[0]
+    d.in_ = xin.data_ptr(); d.wt = packed.data_ptr(); d.scale = sc.data_ptr(); d.shift = sh.data_ptr()
+    d.out = out.data_ptr(); d.tile = tile
+    res_t = None
+    if residual is not None:
+        res_t = torch.from_numpy(residual).to(dev).to(td).contiguous()
+        d.res = res_t.data_ptr(); d.res_cstride = residual.shape[-1]; d.res_coff = 0
+    ext.check(lib.y4_conv2d(C.byref(d), ext.stream_ptr()))
+    torch.cuda.synchronize()
+    full = out.float().cpu().numpy()
+    return full[..., out_pad[0]:out_pad[0] + cout], full
+
+
+def make_conv_weights(rng, cout, cin, k, bn=True):
+    from yolo4hip.weights import ConvWeights
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    if bn:
+        b = np.stack([rng.standard_normal(cout) * 0.2, 1.0 + 0.3 * rng.standard_normal(cout),
+                      0.2 * rng.standard_normal(cout), 0.5 + rng.random(cout)]).astype(np.float32)
+        return ConvWeights(w=w, bn=b)
+    return ConvWeights(w=w, bias=(rng.standard_normal(cout) * 0.5).astype(np.float32))

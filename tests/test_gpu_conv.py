@@ -1,0 +1,101 @@
+"""GPU parity of the implicit-GEMM conv kernel (y4_conv2d through the C ABI) against the oracle's
+conv() unit (oracle/forward.py conv_block <- reference custom_layers.py:5-31,44).
+
+Tolerances (stated per dtype):
+  f32  : |gpu - oracle| <= 2e-5 + 2e-5*|oracle|  (both are fp32 fmaf/sum chains in different orders)
+  bf16 : inputs/weights/residual are first rounded to bf16 and the oracle computes on those in fp32;
+         the GPU result is rounded to bf16 on store -> 1 bf16 ulp (2^-8 relative) + 1e-2 abs slack
+  f16  : same with fp16 (2^-10 relative) + 2e-3 abs
+"""
+import numpy as np
+import pytest
+
+from helpers import make_conv_weights, quantize, run_conv_gpu
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": (2e-5, 2e-5), "bf16": (1e-2, 2.0 ** -7), "f16": (2e-3, 2.0 ** -9)}
+
+# k, stride, cin, cout, side, act, bn, residual, upsample, out_f32, in_pad, out_pad, n
+CASES = [
+    (1, 1, 64, 64, 24, "mish", True, False, False, False, (0, 0), (0, 0), 2),
+    (1, 1, 64, 32, 20, "mish", True, False, False, False, (0, 0), (0, 0), 1),
+    (3, 1, 32, 64, 20, "mish", True, True, False, False, (0, 0), (0, 0), 2),
+    (3, 2, 32, 64, 32, "leaky", True, False, False, False, (0, 0), (0, 0), 1),
+    (3, 1, 128, 256, 19, "leaky", True, False, False, False, (0, 0), (0, 0), 2),
+    (3, 2, 256, 512, 38, "mish", True, False, False, False, (0, 0), (0, 0), 1),
+    (1, 1, 512, 255, 19, None, False, False, False, True, (0, 0), (0, 0), 2),
+    (1, 1, 256, 24, 13, None, False, False, False, True, (0, 0), (0, 0), 3),
+    (1, 1, 512, 256, 13, "leaky", True, False, True, False, (0, 0), (256, 0), 2),
+    (1, 1, 2048, 512, 13, "leaky", True, False, False, False, (0, 0), (0, 0), 1),
+    (1, 1, 128, 64, 26, "mish", True, False, False, False, (64, 64), (64, 0), 1),
+    (3, 1, 64, 64, 26, "mish", True, True, False, False, (0, 64), (0, 64), 1),
+    (3, 2, 128, 256, 26, "leaky", True, False, False, False, (0, 0), (0, 256), 2),
+]
+
+
+def _ref(x, cw, k, stride, act, residual, upsample):
+    from oracle.forward import conv_block
+    y = conv_block(x, cw, k, stride, act, residual)
+    if upsample:
+        y = y.repeat(2, axis=1).repeat(2, axis=2)       # UpSampling2D nearest x2 (custom_layers.py:147)
+    return y
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"k{c[0]}s{c[1]}_{c[2]}to{c[3]}_h{c[4]}")
+def test_conv_vs_oracle(case, dtype):
+    from yolo4hip.weights import ConvWeights
+    k, stride, cin, cout, side, act, bn, use_res, ups, out_f32, in_pad, out_pad, n = case
+    rng = np.random.default_rng(hash((k, stride, cin, cout, side)) % (2 ** 31))
+    x = quantize(rng.standard_normal((n, side, side, cin)).astype(np.float32), dtype)
+    cw = make_conv_weights(rng, cout, cin, k, bn)
+    cwq = ConvWeights(w=quantize(cw.w, dtype), bn=cw.bn, bias=cw.bias)
+    so = side // stride
+    res = quantize(rng.standard_normal((n, so, so, cout)).astype(np.float32), dtype) if use_res else None
+    got, full = run_conv_gpu(x, cwq, k, stride, act, dtype, residual=res, upsample=ups, out_f32=out_f32,
+                             in_pad=in_pad, out_pad=out_pad)
+    want = _ref(x, cwq, k, stride, act, res, ups)
+    atol, rtol = TOL["f32"] if (out_f32 and dtype == "f32") else TOL[dtype]
+    if out_f32 and dtype != "f32":
+        atol, rtol = 1e-4, 1e-4      # fp32 store of an fp32 accumulator over 16-bit inputs
+    err = np.abs(got - want)
+    assert np.all(err <= atol + rtol * np.abs(want)), f"max err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    # the kernel must not touch channels outside its slice (pad channels within the 8-rounded store excepted)
+    cstore = (cout + 7) // 8 * 8
+    if out_pad[0]:
+        assert np.all(full[..., :out_pad[0]] == -5.0)
+    if out_pad[1]:
+        assert np.all(full[..., out_pad[0] + cstore:] == -5.0)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_all_tiles_agree(dtype):
+    """Every tile configuration that fits the shape gives the same result (same K order -> bitwise)."""
+    from yolo4hip import ext
+    from yolo4hip.weights import ConvWeights
+    rng = np.random.default_rng(5)
+    x = quantize(rng.standard_normal((2, 17, 17, 128)).astype(np.float32), dtype)
+    cw = make_conv_weights(rng, 128, 128, 3)
+    cwq = ConvWeights(w=quantize(cw.w, dtype), bn=cw.bn)
+    base, _ = run_conv_gpu(x, cwq, 3, 1, "mish", dtype)
+    ntiles = ext.load().y4_conv_tile_count()
+    ran = 0
+    for tile in range(1, ntiles + 1):
+        try:
+            got, _ = run_conv_gpu(x, cwq, 3, 1, "mish", dtype, tile=tile)
+        except ext.Y4Error as e:
+            assert e.code == -22      # tile does not fit this cin/cout: refused loudly, not computed wrongly
+            continue
+        ran += 1
+        assert np.array_equal(got, base), f"tile {tile} differs: {np.abs(got - base).max()}"
+    assert ran >= 4
+
+
+def test_conv_rejects_bad_shapes():
+    import ctypes as C
+    from yolo4hip import ext
+    lib = ext.load()
+    d = ext.y4_conv_desc()
+    assert lib.y4_conv2d(C.byref(d), None) == -22
+    assert b"null" in lib.y4_last_error()

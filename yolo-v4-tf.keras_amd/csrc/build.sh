@@ -1,0 +1,17 @@
+#!/bin/bash
+# Builds libyolo4hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+OUT=../yolo4hip/libyolo4hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
+mkdir -p build
+pids=()
+for f in conv_igemm misc_kernels decode_nms runtime; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ ../../include/yolo4hip.h -nt build/$f.o ]; then
+    hipcc $FLAGS -c $f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/conv_igemm.o build/misc_kernels.o build/decode_nms.o build/runtime.o
+echo "built $OUT"

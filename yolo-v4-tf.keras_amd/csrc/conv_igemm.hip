@@ -1,0 +1,409 @@
+// conv_igemm.hip -- the reference's conv() unit (custom_layers.py:5-31: Conv2D -> BatchNormalization ->
+// Mish/LeakyReLU) as ONE im2col-free implicit-GEMM MFMA kernel for gfx950, with the graph's glue ops
+// folded into its epilogue: residual Add (custom_layers.py:44), Concatenate (:68,:149,... -> a channel
+// slice store), UpSampling2D (:147,:159 -> 2x2 replicated store).
+//
+// GEMM view (NHWC activations):  D[ch][px] = sum_k Wt[ch][k] * X[px][k],  k = (ky*kw + kx)*Cin + ci
+//   X rows are gathered on the fly: for K-tile (tap, c0) row px is the BK contiguous channels
+//   in[n, ho*s+ky-pad, wo*s+kx-pad, c0:c0+BK]  (zero page when the tap falls in the padding),
+//   copied HBM/L2 -> LDS with global_load_lds (16 B per lane, no VGPR round trip).
+//   Weights are pre-packed [cout_pad][kh][kw][cin] so their K-tile rows are contiguous too.
+// The weight fragment is the MFMA *A* operand and the pixel fragment the *B* operand, so the accumulator
+// layout is D[row = channel][col = pixel]: every lane ends up holding 4*NREP CONSECUTIVE channels of one
+// pixel (the channel <-> MFMA-row assignment is free; it is applied as a row permutation when staging the
+// weight tile), i.e. the NHWC epilogue is 16-byte vector loads/stores with no LDS transpose.
+// LDS rows are BKB (64|128) bytes with the 16-byte chunk index XOR-swizzled by the row so that every
+// ds_read_b128 lane group hits 16 distinct slots; global_load_lds writes LDS lane-linearly, so the
+// swizzle is applied to the per-lane SOURCE address and again on the fragment read (same involution).
+// Pipeline: 2 LDS stages, one barrier per K-tile: loads of tile t+1 fly during the MFMAs of tile t.
+#include "kernels.h"
+
+namespace y4 {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+struct ConvK {
+    const char* in;
+    const char* wt;
+    const float* scale;
+    const float* shift;
+    const char* res;
+    char* out;
+    const char* zero;
+    int N, H, W, Cin, Ho, Wo, cout_store, M, K;
+    int in_cstride, in_coff, out_cstride, out_coff, res_cstride, res_coff;
+    int ksize, stride, pad, act, upsample, out_f32;
+    int grid_m, grid_n;
+};
+
+template <int CPR> __device__ __forceinline__ int swz(int row) {
+    return CPR == 8 ? (row & 7) : ((row >> 1) & 3);
+}
+
+template <int DT> struct Mma;
+template <> struct Mma<Y4_F32> {
+    static __device__ __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[j]), __uint_as_float(x[j]), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<Y4_BF16> {
+    static __device__ __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x),
+                                                      acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<Y4_F16> {
+    static __device__ __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x),
+                                                     acc, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int DT, int BM, int BN, int WM, int WN, int BKB>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int ES = (DT == Y4_F32) ? 4 : 2;
+    constexpr int BK = BKB / ES;            // K elements per tile
+    constexpr int CPR = BKB / 16;           // 16-byte chunks per LDS row
+    constexpr int EPC = 16 / ES;            // elements per chunk
+    constexpr int RPI = NT / CPR;           // rows staged per block-wide load instruction
+    constexpr int A_IT = BM / RPI;
+    constexpr int B_IT = BN >= RPI ? BN / RPI : 1;      // BN < RPI: only the first BN*CPR threads stage weights
+    constexpr bool B_PART = BN < RPI;
+    constexpr int WPX = BM / WM, WCH = BN / WN;
+    constexpr int MREP = WPX / 16, NREP = WCH / 16;
+    constexpr int CPL = 4 * NREP;           // consecutive channels a lane owns
+    constexpr int STAGE = (BM + BN) * BKB;
+    constexpr int KSTEPS = BKB / 64;        // MFMA k-steps (4 chunks each) per tile
+    static_assert(BM % RPI == 0 && (BN % RPI == 0 || (RPI % BN == 0 && (BN * CPR) % 64 == 0)), "tile rows vs rows-per-iteration");
+    static_assert(MREP >= 1 && NREP >= 1, "wave tile");
+    using E = Elem<DT>;
+    using T = typename E::type;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous run of tiles with the
+    //      channel tile fastest, so blocks sharing an activation row panel share an L2 (speed only).
+    const int nwg = p.grid_m * p.grid_n;
+    int t;
+    {
+        const int b = blockIdx.x, qq = nwg >> 3, rr = nwg & 7, xcd = b & 7, idx = b >> 3;
+        t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int tile_m = t / p.grid_n, tile_n = t - tile_m * p.grid_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+
+    // ---- staging set-up: this thread copies physical chunk slot `q` of rows r0 + j*RPI
+    const int q = tid % CPR, r0 = tid / CPR;
+    int a_off[A_IT], a_hi[A_IT], a_wi[A_IT];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) {
+        const int row = r0 + j * RPI;
+        const int m = m0 + row;
+        const int mm = m < p.M ? m : 0;
+        const int n = mm / HoWo, rem = mm - n * HoWo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        a_off[j] = ((n * p.H + hi0) * p.W + wi0) * p.in_cstride + p.in_coff + ((q ^ swz<CPR>(row)) * EPC);
+        a_hi[j] = m < p.M ? hi0 : -100000;     // rows past M never validate -> zero page
+        a_wi[j] = wi0;
+    }
+    const char* b_src[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        const int row = B_PART ? (r0 % BN) : (r0 + j * RPI);
+        // LDS row (wave block, fragment jn, MFMA row i = g*4 + r)  <-  channel g*CPL + jn*4 + r
+        const int wb = row / WCH, pr = row - wb * WCH;
+        const int jn = pr >> 4, i = pr & 15, g = i >> 2, r = i & 3;
+        const int ch = n0 + wb * WCH + g * CPL + jn * 4 + r;
+        b_src[j] = p.wt + ((int64_t)ch * p.K + ((q ^ swz<CPR>(row)) * EPC)) * ES;
+    }
+    char* const lds_a_dst = smem + (wave * 64) * 16;                 // + j*NT*16 (+ lane*16 by hardware)
+    char* const lds_b_dst = smem + BM * BKB + (wave * 64) * 16;
+
+    int ky = 0, kx = 0, c0 = 0;
+    auto stage = [&](int buf) {
+        char* da = lds_a_dst + buf * STAGE;
+        char* db = lds_b_dst + buf * STAGE;
+        const int tap_off = (ky * p.W + kx) * p.in_cstride + c0;
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            const bool ok = (unsigned)(a_hi[j] + ky) < (unsigned)p.H && (unsigned)(a_wi[j] + kx) < (unsigned)p.W;
+            const char* src = ok ? p.in + (int64_t)(a_off[j] + tap_off) * ES : p.zero;
+            glds16(src, da + j * (NT * 16));
+        }
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            if (!B_PART || tid < BN * CPR) glds16(b_src[j], db + j * (NT * 16));     // wave-uniform predicate
+            b_src[j] += BKB;
+        }
+        c0 += BK;
+        if (c0 >= p.Cin) {
+            c0 = 0;
+            if (++kx >= p.ksize) { kx = 0; ++ky; }
+        }
+    };
+
+    // ---- fragment read addresses (row & swizzle depend on the lane only)
+    const int frow = lane & 15, fg = lane >> 4;
+    int xo[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) xo[kk] = frow * BKB + (((kk * 4 + fg) ^ swz<CPR>(frow)) * 16);
+    const char* const lds_x = smem + (wm * WPX) * BKB;
+    const char* const lds_w = smem + BM * BKB + (wn * WCH) * BKB;
+
+    f32x4 acc[MREP][NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // tile kt landed; everyone finished reading the other stage
+        if (kt + 1 < nk) stage((kt + 1) & 1);
+        const char* sx = lds_x + (kt & 1) * STAGE;
+        const char* sw = lds_w + (kt & 1) * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            u32x4 xf[MREP], wf[NREP];
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) xf[i] = *(const u32x4*)(sx + i * 16 * BKB + xo[kk]);
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) wf[j] = *(const u32x4*)(sw + j * 16 * BKB + xo[kk]);
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc[i][j], wf[j], xf[i]);
+        }
+    }
+
+    // ---- epilogue: y = act(acc*scale + shift) (+ residual) -> NHWC slice store (optionally 2x2 replicated)
+    const int chb = n0 + wn * WCH + fg * CPL;       // this lane's first channel
+    float sc[CPL], sh[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c += 4) {
+        const f32x4 s4 = *(const f32x4*)(p.scale + chb + c);
+        const f32x4 h4 = *(const f32x4*)(p.shift + chb + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[c + e] = s4[e]; sh[c + e] = h4[e]; }
+    }
+    constexpr bool FAST = (DT != Y4_F32);
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = m0 + wm * WPX + i * 16 + frow;
+        if (m >= p.M) continue;
+        float v[CPL];
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = j * 4 + r;
+                v[c] = apply_act<FAST>(acc[i][j][r] * sc[c] + sh[c], p.act);
+            }
+        if (p.res) {
+            const T* rp = (const T*)p.res + (int64_t)m * p.res_cstride + p.res_coff + chb;
+#pragma unroll
+            for (int c = 0; c < CPL; c += EPC) {
+                if (chb + c < p.cout_store) {
+                    const u32x4 raw = *(const u32x4*)(rp + c);
+                    const T* rv = (const T*)&raw;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[c + e] += E::ld(rv[e]);
+                }
+            }
+        }
+        int64_t pix[4];
+        int npix = 1;
+        if (p.upsample) {
+            const int n = m / HoWo, rem = m - n * HoWo;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            const int W2 = 2 * p.Wo;
+            const int64_t base = ((int64_t)n * 2 * p.Ho + 2 * ho) * W2 + 2 * wo;
+            pix[0] = base; pix[1] = base + 1; pix[2] = base + W2; pix[3] = base + W2 + 1;
+            npix = 4;
+        } else {
+            pix[0] = m;
+        }
+        for (int u = 0; u < npix; ++u) {
+            if (p.out_f32) {
+                float* op = (float*)p.out + pix[u] * p.out_cstride + p.out_coff + chb;
+#pragma unroll
+                for (int c = 0; c < CPL; c += 4)
+                    if (chb + c < p.cout_store) *(f32x4*)(op + c) = f32x4{v[c], v[c + 1], v[c + 2], v[c + 3]};
+            } else {
+                T* op = (T*)p.out + pix[u] * p.out_cstride + p.out_coff + chb;
+#pragma unroll
+                for (int c = 0; c < CPL; c += EPC) {
+                    if (chb + c < p.cout_store) {
+                        u32x4 raw;
+                        T* ov = (T*)&raw;
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) ov[e] = E::st(v[c + e]);
+                        *(u32x4*)(op + c) = raw;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- launch
+struct TileCfg {
+    int bm, bn, wm, wn, bkb;
+};
+// id 1..N; the table is also what tests sweep through y4_conv_desc.tile
+static const TileCfg kTiles[] = {
+    {128, 128, 2, 2, 128},  // 1
+    {128, 128, 2, 2, 64},   // 2
+    {128, 64, 4, 1, 128},   // 3
+    {128, 64, 4, 1, 64},    // 4
+    {128, 32, 4, 1, 128},   // 5
+    {128, 32, 4, 1, 64},    // 6
+    {256, 128, 4, 2, 128},  // 7
+    {256, 128, 4, 2, 64},   // 8
+    {64, 128, 1, 4, 128},   // 9
+};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+int conv_tile_count() { return kNumTiles; }
+
+template <int DT, int BM, int BN, int WM, int WN, int BKB>
+static int launch_cfg(const ConvK& k, hipStream_t stream) {
+    constexpr int lds = 2 * (BM + BN) * BKB;
+    auto kern = conv_igemm_kernel<DT, BM, BN, WM, WN, BKB>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        Y4_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(k.grid_m * k.grid_n), dim3(64 * WM * WN), lds, stream, k);
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+template <int DT>
+static int launch_dt(int tile, const ConvK& k, hipStream_t s) {
+    switch (tile) {
+        case 1: return launch_cfg<DT, 128, 128, 2, 2, 128>(k, s);
+        case 2: return launch_cfg<DT, 128, 128, 2, 2, 64>(k, s);
+        case 3: return launch_cfg<DT, 128, 64, 4, 1, 128>(k, s);
+        case 4: return launch_cfg<DT, 128, 64, 4, 1, 64>(k, s);
+        case 5: return launch_cfg<DT, 128, 32, 4, 1, 128>(k, s);
+        case 6: return launch_cfg<DT, 128, 32, 4, 1, 64>(k, s);
+        case 7: return launch_cfg<DT, 256, 128, 4, 2, 128>(k, s);
+        case 8: return launch_cfg<DT, 256, 128, 4, 2, 64>(k, s);
+        case 9: return launch_cfg<DT, 64, 128, 1, 4, 128>(k, s);
+    }
+    set_error("conv2d: unknown tile id %d", tile);
+    return Y4_EINVAL;
+}
+
+static bool tile_ok(const TileCfg& tc, int dtype, int cin, int cout_pad) {
+    const int bk = tc.bkb / elem_size(dtype);
+    return cin % bk == 0 && cout_pad % tc.bn == 0;
+}
+
+// Heuristic tile choice (speed only; every valid tile gives the same result up to fp32 summation order
+// -- and the K order is identical across tiles, so results are in fact bitwise equal).
+int conv_pick_tile(int dtype, int M, int cin, int cout) {
+    const int es = elem_size(dtype);
+    const bool k128 = cin % (128 / es) == 0;
+    if (cout <= 32) return k128 ? 5 : 6;
+    if (cout <= 64) return k128 ? 3 : 4;
+    return k128 ? 1 : 2;
+}
+
+int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream) {
+    Y4_REQUIRE(d && d->in && d->wt && d->out && d->scale && d->shift, Y4_EINVAL, "conv2d: null pointer");
+    Y4_REQUIRE(d->dtype >= Y4_F32 && d->dtype <= Y4_F16, Y4_EINVAL, "conv2d: bad dtype %d", d->dtype);
+    Y4_REQUIRE(d->ksize == 1 || d->ksize == 3, Y4_EINVAL, "conv2d: ksize %d (only 1 or 3)", d->ksize);
+    Y4_REQUIRE(d->stride == 1 || (d->stride == 2 && d->ksize == 3), Y4_EINVAL, "conv2d: stride %d", d->stride);
+    Y4_REQUIRE(d->stride == 1 || (d->h % 2 == 0 && d->w % 2 == 0), Y4_EINVAL, "conv2d: stride 2 needs even h,w");
+    Y4_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, Y4_EINVAL, "conv2d: empty shape");
+    const int es = elem_size(d->dtype);
+    const int epc = 16 / es;
+    Y4_REQUIRE(d->cin % (64 / es) == 0, Y4_EINVAL, "conv2d: cin %d must be a multiple of %d for dtype %d",
+               d->cin, 64 / es, d->dtype);
+    Y4_REQUIRE(d->in_cstride % epc == 0 && d->in_coff % epc == 0, Y4_EINVAL, "conv2d: input view not 16-byte aligned");
+    const int oepc = d->out_f32 ? 4 : epc;
+    Y4_REQUIRE(d->out_cstride % oepc == 0 && d->out_coff % oepc == 0, Y4_EINVAL,
+               "conv2d: output view not 16-byte aligned");
+    Y4_REQUIRE(!d->res || (d->res_cstride % epc == 0 && d->res_coff % epc == 0), Y4_EINVAL,
+               "conv2d: residual view not 16-byte aligned");
+    ConvK k{};
+    k.in = (const char*)d->in; k.wt = (const char*)d->wt; k.scale = d->scale; k.shift = d->shift;
+    k.res = (const char*)d->res; k.out = (char*)d->out; k.zero = zero_page;
+    k.N = d->n; k.H = d->h; k.W = d->w; k.Cin = d->cin;
+    k.Ho = d->h / d->stride; k.Wo = d->w / d->stride;
+    k.cout_store = (int)round_up(d->cout, 8);
+    Y4_REQUIRE((int64_t)d->n * k.Ho * k.Wo < (1ll << 31), Y4_EINVAL, "conv2d: too many output pixels");
+    k.M = d->n * k.Ho * k.Wo;
+    k.K = d->ksize * d->ksize * d->cin;
+    Y4_REQUIRE((int64_t)d->n * d->h * d->w * d->in_cstride < (1ll << 31), Y4_EINVAL, "conv2d: input too large");
+    k.in_cstride = d->in_cstride; k.in_coff = d->in_coff;
+    k.out_cstride = d->out_cstride; k.out_coff = d->out_coff;
+    k.res_cstride = d->res_cstride; k.res_coff = d->res_coff;
+    k.ksize = d->ksize; k.stride = d->stride; k.pad = d->ksize == 3 ? 1 : 0;
+    k.act = d->act; k.upsample = d->upsample; k.out_f32 = d->out_f32;
+    const int cout_pad = (int)round_up(d->cout, COUT_PAD);
+    int tile = d->tile ? d->tile : conv_pick_tile(d->dtype, k.M, d->cin, d->cout);
+    Y4_REQUIRE(tile >= 1 && tile <= kNumTiles, Y4_EINVAL, "conv2d: tile id %d out of range", tile);
+    const TileCfg& tc = kTiles[tile - 1];
+    Y4_REQUIRE(tile_ok(tc, d->dtype, d->cin, cout_pad), Y4_EINVAL,
+               "conv2d: tile %d (bk bytes %d, bn %d) does not fit cin %d / cout_pad %d", tile, tc.bkb, tc.bn,
+               d->cin, cout_pad);
+    k.grid_m = (k.M + tc.bm - 1) / tc.bm;
+    k.grid_n = (int)((round_up(d->cout, 8) + tc.bn - 1) / tc.bn);
+    switch (d->dtype) {
+        case Y4_F32: return launch_dt<Y4_F32>(tile, k, stream);
+        case Y4_BF16: return launch_dt<Y4_BF16>(tile, k, stream);
+        default: return launch_dt<Y4_F16>(tile, k, stream);
+    }
+}
+
+// ------------------------------------------------------------------------------ weight re-layout
+template <int DT>
+__global__ void pack_conv_kernel(const float* __restrict__ w, typename Elem<DT>::type* __restrict__ out, int cout,
+                                 int cout_pad, int cin, int kk) {
+    const int64_t total = (int64_t)cout_pad * kk * cin;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin);
+        const int64_t r = i / cin;
+        const int tap = (int)(r % kk), co = (int)(r / kk);
+        const float v = co < cout ? w[((int64_t)co * cin + ci) * kk + tap] : 0.f;
+        out[i] = Elem<DT>::st(v);
+    }
+}
+
+int pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw, void* packed, hipStream_t stream) {
+    const int cout_pad = (int)round_up(cout, COUT_PAD), kk = ksize * ksize;
+    const int64_t total = (int64_t)cout_pad * kk * cin;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    switch (dtype) {
+        case Y4_F32: hipLaunchKernelGGL(pack_conv_kernel<Y4_F32>, dim3(blocks), dim3(256), 0, stream, oihw, (float*)packed, cout, cout_pad, cin, kk); break;
+        case Y4_BF16: hipLaunchKernelGGL(pack_conv_kernel<Y4_BF16>, dim3(blocks), dim3(256), 0, stream, oihw, (uint16_t*)packed, cout, cout_pad, cin, kk); break;
+        case Y4_F16: hipLaunchKernelGGL(pack_conv_kernel<Y4_F16>, dim3(blocks), dim3(256), 0, stream, oihw, (_Float16*)packed, cout, cout_pad, cin, kk); break;
+        default: set_error("pack_conv_weights: bad dtype %d", dtype); return Y4_EINVAL;
+    }
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+}  // namespace y4

@@ -1,0 +1,296 @@
+// decode_nms.hip -- the tail of the reference's inference_model (models.py:68-73):
+//   yolov4_head/get_boxes (custom_layers.py:201-258)  -> decode_kernel
+//   nms() = tf.image.combined_non_max_suppression (custom_layers.py:261-298) -> nms_kernel
+//
+// decode_kernel: one wavefront per grid cell.  The cell's 3*(5+C) raw logits are one contiguous run of the
+// NHWC head, read coalesced into LDS; lanes then sweep the (anchor, class) pairs, form
+// score = sigmoid(obj)*sigmoid(cls) and append the ones with score > score_threshold (strict) to the
+// image's candidate list with ONE wave-aggregated atomic (ballot + mbcnt).  Lanes 0..2 decode the three
+// boxes.  A candidate is a 64-bit key  (score bits << 32) | ~(box_index*C + class): sorting keys
+// descending gives (score desc, box index asc, class asc) -- the tie order this build defines.
+//
+// nms_kernel: one workgroup per image.  Class-aware greedy NMS is done in ONE pass over the globally
+// sorted candidates (suppression only against kept boxes of the same class): this visits every class's
+// candidates in that class's own descending order, so the per-class kept sets equal TensorFlow's
+// per-class greedy runs, and the kept boxes come out already in the final descending-score order; the
+// pass stops after max_total kept boxes (a class's 101st kept box can never be in the overall top 100, so
+// max_per_class is enforced with a same-class count).  Candidates are taken in chunks of at most SORT_CAP
+// in descending key order (radix-select of the chunk pivot when an image has more than SORT_CAP
+// candidates), bitonic-sorted in LDS, their boxes gathered into LDS, then scanned by wave 0: the candidate
+// is compared against the <=max_total kept boxes in parallel across lanes and the verdict is a ballot.
+// IoU is TensorFlow's: corners min/max-normalised, 0 if either area <= 0, suppress iff IoU > threshold.
+#include "kernels.h"
+
+#pragma clang fp contract(off)   // keep the reference's float32 op order (no fused multiply-add)
+
+namespace y4 {
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeK p) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t cell = (int64_t)blockIdx.x * 4 + wave;
+    if (cell >= (int64_t)p.N * p.cells_per_img) return;
+    const int n = (int)(cell / p.cells_per_img);
+    int rem = (int)(cell - (int64_t)n * p.cells_per_img);
+    int s = 0;
+    if (rem >= p.g[0] * p.g[0]) { rem -= p.g[0] * p.g[0]; s = 1; if (rem >= p.g[1] * p.g[1]) { rem -= p.g[1] * p.g[1]; s = 2; } }
+    const int g = p.g[s];
+    const int row = rem / g, col = rem - row * g;
+    const int nf = 5 + p.C, nval = 3 * nf;
+    float* v = dsm + wave * p.hcs;
+    const float* src = p.head[s] + ((int64_t)(n * g + row) * g + col) * p.hcs;
+    for (int e = lane; e < nval; e += 64) v[e] = src[e];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);     // LDS writes of this wave are done (single-wave region, no s_barrier)
+    __builtin_amdgcn_wave_barrier();
+
+    const int box0 = p.box_off[s] + (row * g + col) * 3;
+    if (lane < 3) {
+        // custom_layers.py:251-256
+        const float* t = v + lane * nf;
+        const float bx = ((sigmoid_f(t[0]) * p.xyscale[s]) - p.xyoff[s] + (float)col) * (float)p.stride[s];
+        const float by = ((sigmoid_f(t[1]) * p.xyscale[s]) - p.xyoff[s] + (float)row) * (float)p.stride[s];
+        const float bw = expf(t[2]) * p.anchors[(s * 3 + lane) * 2 + 0];
+        const float bh = expf(t[3]) * p.anchors[(s * 3 + lane) * 2 + 1];
+        float4 o;
+        o.x = (bx - bw / 2.0f) / p.img_size;
+        o.y = (by - bh / 2.0f) / p.img_size;
+        o.z = (bx + bw / 2.0f) / p.img_size;
+        o.w = (by + bh / 2.0f) / p.img_size;
+        *(float4*)(p.dboxes + ((int64_t)n * p.nbox + box0 + lane) * 4) = o;
+    }
+    const float obj0 = sigmoid_f(v[4]), obj1 = sigmoid_f(v[nf + 4]), obj2 = sigmoid_f(v[2 * nf + 4]);
+    unsigned long long* keys = p.keys + (int64_t)n * p.cap;
+    for (int e0 = 0; e0 < nval; e0 += 64) {
+        const int e = e0 + lane;
+        bool hit = false;
+        unsigned long long key = 0;
+        if (e < nval) {
+            const int a = e / nf, f = e - a * nf;
+            if (f >= 5) {
+                const float sc = (a == 0 ? obj0 : (a == 1 ? obj1 : obj2)) * sigmoid_f(v[e]);
+                if (sc > p.score_thr) {
+                    hit = true;
+                    const uint32_t id = (uint32_t)(box0 + a) * (uint32_t)p.C + (uint32_t)(f - 5);
+                    key = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(~id);
+                }
+            }
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(p.counts + n, (uint32_t)__popcll(mask));
+            base = __shfl(base, 0);
+            if (hit) {
+                const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < p.cap) keys[pos] = key;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- NMS
+constexpr int NMS_THREADS = 1024;
+constexpr int SORT_CAP = 4096;
+
+__device__ __forceinline__ float iou_tf(const float4 a, const float4 b) {
+    const float ay0 = fminf(a.x, a.z), ax0 = fminf(a.y, a.w), ay1 = fmaxf(a.x, a.z), ax1 = fmaxf(a.y, a.w);
+    const float by0 = fminf(b.x, b.z), bx0 = fminf(b.y, b.w), by1 = fmaxf(b.x, b.z), bx1 = fmaxf(b.y, b.w);
+    const float area_a = (ay1 - ay0) * (ax1 - ax0);
+    const float area_b = (by1 - by0) * (bx1 - bx0);
+    if (area_a <= 0.f || area_b <= 0.f) return 0.f;
+    const float iy0 = fmaxf(ay0, by0), ix0 = fmaxf(ax0, bx0), iy1 = fminf(ay1, by1), ix1 = fminf(ax1, bx1);
+    const float inter = fmaxf(iy1 - iy0, 0.f) * fmaxf(ix1 - ix0, 0.f);
+    return inter / (area_a + area_b - inter);
+}
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
+    extern __shared__ __attribute__((aligned(16))) char nsm[];
+    unsigned long long* skey = (unsigned long long*)nsm;                  // SORT_CAP
+    float4* sbox = (float4*)(nsm + SORT_CAP * 8);                          // SORT_CAP
+    float4* kbox = (float4*)(nsm + SORT_CAP * 24);                         // max_total
+    int* kcls = (int*)(kbox + p.max_total);                                // max_total
+    float* kscore = (float*)(kcls + p.max_total);                          // max_total
+    int* kidx = (int*)(kscore + p.max_total);                              // max_total
+    uint32_t* hist = (uint32_t*)(kidx + p.max_total);                      // 256
+    uint32_t* sh = hist + 256;                                             // scratch words
+    // sh[0]=count in chunk, sh[1]=kept, sh[2]=remaining below cutoff, sh[3..4]=pivot lo/hi, sh[5]=need
+
+    const int n = blockIdx.x, tid = threadIdx.x;
+    uint32_t cnt = p.counts[n];
+    if (cnt > p.cap) {
+        if (tid == 0) atomicOr(p.status, 1u);
+        cnt = p.cap;
+    }
+    const unsigned long long* gk = p.keys + (int64_t)n * p.cap;
+    const float* gb = p.dboxes + (int64_t)n * p.nbox * 4;
+    if (tid == 0) sh[1] = 0;
+    unsigned long long cutoff = ~0ull;           // exclusive upper bound of keys still to visit
+    __syncthreads();
+
+    while (true) {
+        // ---- how many keys remain below the cutoff?
+        if (tid == 0) sh[2] = 0;
+        __syncthreads();
+        {
+            uint32_t local = 0;
+            for (uint32_t i = tid; i < cnt; i += NMS_THREADS) local += gk[i] < cutoff ? 1u : 0u;
+            for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+            if ((tid & 63) == 0 && local) atomicAdd(&sh[2], local);
+        }
+        __syncthreads();
+        const uint32_t remaining = sh[2];
+        if (remaining == 0) break;
+        // ---- pivot = SORT_CAP-th largest key below the cutoff (0 when everything fits)
+        unsigned long long pivot = 0;
+        if (remaining > SORT_CAP) {
+            unsigned long long prefix = 0, pmask = 0;
+            uint32_t need = SORT_CAP;
+            for (int shift = 56; shift >= 0; shift -= 8) {
+                for (int i = tid; i < 256; i += NMS_THREADS) hist[i] = 0;
+                __syncthreads();
+                for (uint32_t i = tid; i < cnt; i += NMS_THREADS) {
+                    const unsigned long long k = gk[i];
+                    if (k < cutoff && (k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t acc = 0;
+                    int d = 255;
+                    for (; d > 0; --d) {
+                        if (acc + hist[d] >= need) break;
+                        acc += hist[d];
+                    }
+                    sh[5] = need - acc;                  // still needed inside digit d
+                    sh[3] = (uint32_t)d;
+                }
+                __syncthreads();
+                need = sh[5];
+                prefix |= (unsigned long long)sh[3] << shift;
+                pmask |= 255ull << shift;
+                __syncthreads();
+            }
+            pivot = prefix;                               // keys are unique: exactly SORT_CAP keys in [pivot, cutoff)
+        }
+        // ---- gather the chunk, sort it descending
+        if (tid == 0) sh[0] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += NMS_THREADS) {
+            const unsigned long long k = gk[i];
+            if (k < cutoff && k >= pivot) {
+                const uint32_t pos = atomicAdd(&sh[0], 1u);
+                if (pos < SORT_CAP) skey[pos] = k;
+            }
+        }
+        __syncthreads();
+        const uint32_t m = sh[0] < SORT_CAP ? sh[0] : SORT_CAP;
+        uint32_t m2 = 64;
+        while (m2 < m) m2 <<= 1;
+        for (uint32_t i = m + tid; i < m2; i += NMS_THREADS) skey[i] = 0;
+        __syncthreads();
+        for (uint32_t k = 2; k <= m2; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = tid; i < m2; i += NMS_THREADS) {
+                    const uint32_t l = i ^ j;
+                    if (l > i) {
+                        const unsigned long long a = skey[i], b = skey[l];
+                        const bool desc = (i & k) == 0;
+                        if (desc ? a < b : a > b) { skey[i] = b; skey[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ---- gather the chunk's boxes into LDS
+        for (uint32_t i = tid; i < m; i += NMS_THREADS) {
+            const uint32_t id = ~(uint32_t)(skey[i] & 0xffffffffull);
+            sbox[i] = *(const float4*)(gb + (int64_t)(id / (uint32_t)p.C) * 4);
+        }
+        __syncthreads();
+        // ---- greedy pass (wave 0)
+        if (tid < 64) {
+            int kept = (int)sh[1];
+            for (uint32_t t = 0; t < m && kept < p.max_total; ++t) {
+                const unsigned long long key = skey[t];
+                const uint32_t id = ~(uint32_t)(key & 0xffffffffull);
+                const int cls = (int)(id % (uint32_t)p.C);
+                const float4 cb = sbox[t];
+                bool sup = false;
+                int same = 0;
+                for (int j = tid; j < kept; j += 64) {
+                    if (kcls[j] == cls) {
+                        ++same;
+                        sup = sup || (iou_tf(cb, kbox[j]) > p.iou_thr);
+                    }
+                }
+                const bool any_sup = __ballot(sup) != 0ull;
+                for (int o = 32; o > 0; o >>= 1) same += __shfl_xor(same, o);
+                if (!any_sup && same < p.max_per_class) {
+                    if (tid == 0) {
+                        kbox[kept] = cb;
+                        kcls[kept] = cls;
+                        kscore[kept] = __uint_as_float((uint32_t)(key >> 32));
+                        kidx[kept] = (int)(id / (uint32_t)p.C);
+                    }
+                    ++kept;
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_s_waitcnt(0);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (tid == 0) sh[1] = (uint32_t)kept;
+        }
+        __syncthreads();
+        if ((int)sh[1] >= p.max_total || pivot == 0) break;
+        cutoff = pivot;
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- outputs: clipped boxes, zero padded (clip_boxes=True, pad to max_total)
+    const int kept = (int)sh[1];
+    for (int i = tid; i < p.max_total; i += NMS_THREADS) {
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        float s = 0.f, c = 0.f;
+        int id = -1;
+        if (i < kept) {
+            b = kbox[i];
+            b.x = fmaxf(fminf(b.x, 1.f), 0.f); b.y = fmaxf(fminf(b.y, 1.f), 0.f);
+            b.z = fmaxf(fminf(b.z, 1.f), 0.f); b.w = fmaxf(fminf(b.w, 1.f), 0.f);
+            s = kscore[i]; c = (float)kcls[i]; id = kidx[i];
+        }
+        *(float4*)(p.out_boxes + ((int64_t)n * p.max_total + i) * 4) = b;
+        p.out_scores[(int64_t)n * p.max_total + i] = s;
+        p.out_classes[(int64_t)n * p.max_total + i] = c;
+        if (p.out_idx) p.out_idx[(int64_t)n * p.max_total + i] = id;
+    }
+    if (tid == 0) p.out_valid[n] = kept;
+}
+
+size_t nms_lds_bytes(int max_total) { return (size_t)SORT_CAP * 24 + (size_t)max_total * (16 + 12) + 256 * 4 + 64; }
+
+int decode_launch(const DecodeK& k, hipStream_t stream) {
+    Y4_CHECK_HIP(hipMemsetAsync(k.counts, 0, sizeof(uint32_t) * k.N, stream));
+    const int64_t cells = (int64_t)k.N * k.cells_per_img;
+    const int blocks = (int)((cells + 3) / 4);
+    const size_t lds = (size_t)4 * k.hcs * sizeof(float);
+    hipLaunchKernelGGL(decode_kernel, dim3(blocks), dim3(256), lds, stream, k);
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+int nms_launch(const NmsK& k, hipStream_t stream) {
+    const size_t lds = nms_lds_bytes(k.max_total);
+    static bool attr_set = false;
+    if (!attr_set) {
+        Y4_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    Y4_REQUIRE(lds <= 160 * 1024, Y4_EINVAL, "nms: max_total %d needs %zu bytes of LDS", k.max_total, lds);
+    hipLaunchKernelGGL(nms_kernel, dim3(k.N), dim3(NMS_THREADS), lds, stream, k);
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+}  // namespace y4

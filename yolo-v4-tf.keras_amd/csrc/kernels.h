@@ -1,0 +1,53 @@
+// kernels.h -- launch-side interface between runtime.hip and the kernel files.
+#pragma once
+#include "common.h"
+
+namespace y4 {
+
+// conv_igemm.hip
+int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream);
+int conv_tile_count();
+int conv_pick_tile(int dtype, int M, int cin, int cout);
+int pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw, void* packed, hipStream_t stream);
+
+// misc_kernels.hip
+int stem_conv_launch(int dtype, const float* imgs, int n, int h, int w, const float* w_oihw, const float* scale,
+                     const float* shift, int cout, int act, void* out, int out_cstride, int out_coff, hipStream_t stream);
+int spp_launch(int dtype, void* buf, int n, int side, int c, hipStream_t stream);
+int view_to_f32_launch(int dtype, const void* src, float* dst, int64_t pixels, int cstride, int coff, int c,
+                       hipStream_t stream);
+int f32_to_view_launch(const float* src, float* dst, int64_t pixels, int cstride, int c, hipStream_t stream);
+int fold_bn_launch(const float* rec, float* scale, float* shift, int cout, int cout_pad, int has_bn, hipStream_t stream);
+
+// decode_nms.hip
+struct DecodeK {
+    const float* head[3];
+    int g[3], stride[3], box_off[3];
+    float xyscale[3], xyoff[3];      // xyoff = float(0.5*(xyscale-1)) computed in double like the reference
+    float anchors[18];
+    int cells_per_img;               // g0^2 + g1^2 + g2^2
+    int N, C, hcs, nbox;
+    float img_size, score_thr;
+    float* dboxes;                   // [N, nbox, 4] normalised x1,y1,x2,y2
+    unsigned long long* keys;        // [N, cap]
+    uint32_t* counts;                // [N]
+    uint32_t cap;
+};
+struct NmsK {
+    const float* dboxes;             // [N, nbox, 4]
+    const unsigned long long* keys;  // [N, cap]
+    const uint32_t* counts;          // [N]
+    uint32_t cap;
+    int N, C, nbox, max_total, max_per_class;
+    float iou_thr;
+    float* out_boxes;                // [N, max_total, 4]
+    float* out_scores;               // [N, max_total]
+    float* out_classes;              // [N, max_total]
+    int32_t* out_valid;              // [N]
+    int32_t* out_idx;                // [N, max_total] or null
+    uint32_t* status;                // [1] bit0: candidate list overflowed its capacity
+};
+int decode_launch(const DecodeK& k, hipStream_t stream);
+int nms_launch(const NmsK& k, hipStream_t stream);
+
+}  // namespace y4

@@ -1,0 +1,244 @@
+// misc_kernels.hip -- the non-GEMM kernels of the forward pass:
+//   stem conv (reference custom_layers.py:101: conv(input, 32, 3), Cin = 3 -> K = 27, too thin for MFMA tiles)
+//   SPP max-pools + concat (reference custom_layers.py:130-134)
+//   view -> dense float32 copies (what Keras returns from yolo_model.predict, reference models.py:514)
+#include "kernels.h"
+
+namespace y4 {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+// ------------------------------------------------------------------------------------------ stem
+// One thread = one output pixel x all COUT(32) channels; weights [27][COUT] broadcast from LDS.
+// HBM-bound by design: reads 12 B/pixel (fp32 RGB), writes COUT*sizeof(T) per pixel, fully coalesced.
+template <int DT, int COUT>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ w_oihw,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        typename Elem<DT>::type* __restrict__ out, int N, int H, int W,
+                                                        int out_cstride, int out_coff, int act) {
+    using E = Elem<DT>;
+    using T = typename E::type;
+    __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
+    __shared__ __attribute__((aligned(16))) float ss[2 * COUT];
+    for (int i = threadIdx.x; i < 27 * COUT; i += 256) {
+        // ws[(ky*3+kx)*3 + ci][co]  <-  w[co][ci][ky][kx]
+        const int co = i % COUT, k = i / COUT;
+        const int ci = k % 3, tap = k / 3;
+        ws[i] = w_oihw[(co * 3 + ci) * 9 + tap];
+    }
+    for (int i = threadIdx.x; i < COUT; i += 256) { ss[i] = scale[i]; ss[COUT + i] = shift[i]; }
+    __syncthreads();
+    const int64_t total = (int64_t)N * H * W;
+    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= total) return;
+    const int x = (int)(pix % W);
+    const int64_t r = pix / W;
+    const int y = (int)(r % H), n = (int)(r / H);
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xx = x + kx - 1;
+            const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const float* ip = img + (((int64_t)n * H + (ok ? yy : 0)) * W + (ok ? xx : 0)) * 3;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float v = ok ? ip[ci] : 0.f;
+                const float* wk = ws + ((ky * 3 + kx) * 3 + ci) * COUT;
+#pragma unroll
+                for (int c = 0; c < COUT; c += 4) {
+                    const f32x4 w4 = *(const f32x4*)(wk + c);
+                    acc[c] = fmaf(v, w4[0], acc[c]);
+                    acc[c + 1] = fmaf(v, w4[1], acc[c + 1]);
+                    acc[c + 2] = fmaf(v, w4[2], acc[c + 2]);
+                    acc[c + 3] = fmaf(v, w4[3], acc[c + 3]);
+                }
+            }
+        }
+    }
+    constexpr int EPC = 16 / (int)sizeof(T);
+    T* op = out + pix * out_cstride + out_coff;
+    constexpr bool FAST = (DT != Y4_F32);
+#pragma unroll
+    for (int c = 0; c < COUT; c += EPC) {
+        u32x4 raw;
+        T* ov = (T*)&raw;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) ov[e] = E::st(apply_act<FAST>(acc[c + e] * ss[c + e] + ss[COUT + c + e], act));
+        *(u32x4*)(op + c) = raw;
+    }
+}
+
+int stem_conv_launch(int dtype, const float* imgs, int n, int h, int w, const float* w_oihw, const float* scale,
+                     const float* shift, int cout, int act, void* out, int out_cstride, int out_coff,
+                     hipStream_t stream) {
+    Y4_REQUIRE(cout == 32, Y4_EINVAL, "stem_conv: cout %d (the plan's stem has 32 filters)", cout);
+    Y4_REQUIRE(imgs && w_oihw && scale && shift && out, Y4_EINVAL, "stem_conv: null pointer");
+    const int epc = 16 / elem_size(dtype);
+    Y4_REQUIRE(out_cstride % epc == 0 && out_coff % epc == 0, Y4_EINVAL, "stem_conv: output view not 16-byte aligned");
+    const int64_t total = (int64_t)n * h * w;
+    const int blocks = (int)((total + 255) / 256);
+    switch (dtype) {
+        case Y4_F32: hipLaunchKernelGGL((stem_conv_kernel<Y4_F32, 32>), dim3(blocks), dim3(256), 0, stream, imgs, w_oihw, scale, shift, (float*)out, n, h, w, out_cstride, out_coff, act); break;
+        case Y4_BF16: hipLaunchKernelGGL((stem_conv_kernel<Y4_BF16, 32>), dim3(blocks), dim3(256), 0, stream, imgs, w_oihw, scale, shift, (uint16_t*)out, n, h, w, out_cstride, out_coff, act); break;
+        case Y4_F16: hipLaunchKernelGGL((stem_conv_kernel<Y4_F16, 32>), dim3(blocks), dim3(256), 0, stream, imgs, w_oihw, scale, shift, (_Float16*)out, n, h, w, out_cstride, out_coff, act); break;
+        default: set_error("stem_conv: bad dtype %d", dtype); return Y4_EINVAL;
+    }
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+// ------------------------------------------------------------------------------------------- SPP
+// buf [n, side, side, 4c]: x lives in channels [3c,4c); writes maxpool13 -> [0,c), maxpool9 -> [c,2c),
+// maxpool5 -> [2c,3c).  stride 1, 'same': windows are clipped at the border (Keras pads with -inf).
+// The 5/9/13 windows are nested, so one sweep of the 13x13 neighbourhood yields all three maxima.
+template <int DT>
+__global__ __launch_bounds__(256) void spp_kernel(typename Elem<DT>::type* __restrict__ buf, int N, int S, int C) {
+    using E = Elem<DT>;
+    using T = typename E::type;
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int cchunks = C / EPC;
+    const int64_t total = (int64_t)N * S * S * cchunks;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cc = (int)(i % cchunks);
+    int64_t r = i / cchunks;
+    const int x = (int)(r % S); r /= S;
+    const int y = (int)(r % S);
+    const int n = (int)(r / S);
+    const int cs = 4 * C;
+    float m5[EPC], m9[EPC], m13[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) m5[e] = m9[e] = m13[e] = -INFINITY;
+    const T* base = buf + (int64_t)n * S * S * cs + 3 * C + cc * EPC;
+    for (int dy = -6; dy <= 6; ++dy) {
+        const int yy = y + dy;
+        if ((unsigned)yy >= (unsigned)S) continue;
+        const int ady = dy < 0 ? -dy : dy;
+        for (int dx = -6; dx <= 6; ++dx) {
+            const int xx = x + dx;
+            if ((unsigned)xx >= (unsigned)S) continue;
+            const int adx = dx < 0 ? -dx : dx;
+            const int rad = ady > adx ? ady : adx;
+            const u32x4 raw = *(const u32x4*)(base + ((int64_t)yy * S + xx) * cs);
+            const T* v = (const T*)&raw;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float f = E::ld(v[e]);
+                m13[e] = fmaxf(m13[e], f);
+                if (rad <= 4) m9[e] = fmaxf(m9[e], f);
+                if (rad <= 2) m5[e] = fmaxf(m5[e], f);
+            }
+        }
+    }
+    T* op = buf + (((int64_t)n * S + y) * S + x) * cs + cc * EPC;
+    u32x4 o13, o9, o5;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        ((T*)&o13)[e] = E::st(m13[e]);
+        ((T*)&o9)[e] = E::st(m9[e]);
+        ((T*)&o5)[e] = E::st(m5[e]);
+    }
+    *(u32x4*)(op) = o13;
+    *(u32x4*)(op + C) = o9;
+    *(u32x4*)(op + 2 * C) = o5;
+}
+
+int spp_launch(int dtype, void* buf, int n, int side, int c, hipStream_t stream) {
+    Y4_REQUIRE(buf && n > 0 && side > 0, Y4_EINVAL, "spp: bad arguments");
+    const int epc = 16 / elem_size(dtype);
+    Y4_REQUIRE(c % epc == 0, Y4_EINVAL, "spp: channels %d not a multiple of %d", c, epc);
+    const int64_t total = (int64_t)n * side * side * (c / epc);
+    const int blocks = (int)((total + 255) / 256);
+    switch (dtype) {
+        case Y4_F32: hipLaunchKernelGGL(spp_kernel<Y4_F32>, dim3(blocks), dim3(256), 0, stream, (float*)buf, n, side, c); break;
+        case Y4_BF16: hipLaunchKernelGGL(spp_kernel<Y4_BF16>, dim3(blocks), dim3(256), 0, stream, (uint16_t*)buf, n, side, c); break;
+        case Y4_F16: hipLaunchKernelGGL(spp_kernel<Y4_F16>, dim3(blocks), dim3(256), 0, stream, (_Float16*)buf, n, side, c); break;
+        default: set_error("spp: bad dtype %d", dtype); return Y4_EINVAL;
+    }
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+// ----------------------------------------------------------------------- view -> dense float32 copy
+template <int DT>
+__global__ void view_to_f32_kernel(const typename Elem<DT>::type* __restrict__ src, float* __restrict__ dst,
+                                   int64_t pixels, int cstride, int coff, int c) {
+    const int64_t total = pixels * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t px = i / c;
+        const int ch = (int)(i - px * c);
+        dst[i] = Elem<DT>::ld(src[px * cstride + coff + ch]);
+    }
+}
+
+int view_to_f32_launch(int dtype, const void* src, float* dst, int64_t pixels, int cstride, int coff, int c,
+                       hipStream_t stream) {
+    const int64_t total = pixels * c;
+    if (total == 0) return Y4_OK;
+    const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    switch (dtype) {
+        case Y4_F32: hipLaunchKernelGGL(view_to_f32_kernel<Y4_F32>, dim3(blocks), dim3(256), 0, stream, (const float*)src, dst, pixels, cstride, coff, c); break;
+        case Y4_BF16: hipLaunchKernelGGL(view_to_f32_kernel<Y4_BF16>, dim3(blocks), dim3(256), 0, stream, (const uint16_t*)src, dst, pixels, cstride, coff, c); break;
+        case Y4_F16: hipLaunchKernelGGL(view_to_f32_kernel<Y4_F16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)src, dst, pixels, cstride, coff, c); break;
+        default: set_error("view_to_f32: bad dtype %d", dtype); return Y4_EINVAL;
+    }
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+// dense float32 [pixels, c] -> float32 view (pad channels zeroed); used to inject raw heads for decode/NMS tests
+__global__ void f32_to_view_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t pixels, int cstride,
+                                   int c) {
+    const int64_t total = pixels * cstride;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t px = i / cstride;
+        const int ch = (int)(i - px * cstride);
+        dst[i] = ch < c ? src[px * c + ch] : 0.f;
+    }
+}
+
+int f32_to_view_launch(const float* src, float* dst, int64_t pixels, int cstride, int c, hipStream_t stream) {
+    const int64_t total = pixels * cstride;
+    if (total == 0) return Y4_OK;
+    const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(f32_to_view_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, pixels, cstride, c);
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+// per-channel BN fold: scale = gamma*rsqrt(var+eps), shift = beta - mean*scale  (Keras eps 1e-3), or the
+// head convs' (1, bias).  rows of `bn` are Darknet order [beta, gamma, mean, var] (reference utils.py:28-31).
+__global__ void fold_bn_kernel(const float* __restrict__ rec, float* __restrict__ scale, float* __restrict__ shift,
+                               int cout, int cout_pad, int has_bn) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cout_pad) return;
+    float s = 1.f, h = 0.f;
+    if (c < cout) {
+        if (has_bn) {
+            const float beta = rec[c], gamma = rec[cout + c], mean = rec[2 * cout + c], var = rec[3 * cout + c];
+            s = gamma * (1.0f / sqrtf(var + 1e-3f));
+            h = beta - mean * s;
+        } else {
+            h = rec[c];
+        }
+    } else {
+        s = 0.f;
+    }
+    scale[c] = s;
+    shift[c] = h;
+}
+
+int fold_bn_launch(const float* rec, float* scale, float* shift, int cout, int cout_pad, int has_bn, hipStream_t stream) {
+    hipLaunchKernelGGL(fold_bn_kernel, dim3((cout_pad + 255) / 256), dim3(256), 0, stream, rec, scale, shift, cout,
+                       cout_pad, has_bn);
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+}  // namespace y4

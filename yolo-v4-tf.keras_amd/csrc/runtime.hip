@@ -1,0 +1,559 @@
+// runtime.hip -- host side of libyolo4hip: the C ABI of include/yolo4hip.h, the 110-conv plan
+// (reference custom_layers.py:100-198 cspdarknet53 + yolov4_neck), the buffer plan and the executor.
+//
+// Plan notes
+//  * conv index == call order below == Keras creation order == Darknet blob order (reference utils.py:19-21).
+//  * every Concatenate of the reference is realised as ONE NHWC buffer whose channel slices are written in
+//    place by the producing convs; UpSampling2D is the 2x2-replicating store of the
+//    producing 1x1 conv; each residual Add is the epilogue of its 3x3 conv.
+//  * activations for max_batch images are carved out of the caller's workspace once, at bind time.
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "kernels.h"
+
+namespace y4 {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct View {
+    int buf = -1;          // buffer id
+    int side = 0, cstride = 0, coff = 0, c = 0;
+};
+struct Buffer {
+    int side, channels;
+    bool f32;              // raw heads are float32 whatever the compute dtype
+    size_t offset = 0;     // byte offset in the act workspace (for max_batch images)
+    size_t bytes = 0;
+};
+enum OpKind { OP_STEM, OP_CONV, OP_SPP };
+struct Op {
+    OpKind kind;
+    int conv = -1;
+    View in, out, res;
+    bool has_res = false, upsample = false, out_f32 = false;
+    char name[16];
+};
+struct Layer {
+    y4_layer_desc d;
+    int cout_pad;
+    size_t w_off, scale_off, shift_off;   // byte offsets in the wts workspace
+};
+
+}  // namespace y4
+
+using namespace y4;
+
+struct y4_ctx {
+    y4_config cfg;
+    int es;                           // element size of the compute dtype
+    int S;                            // img side
+    int hcs;                          // padded channels of a raw head
+    int nbox;
+    int64_t flops_per_image = 0;
+    int64_t weight_floats = 0;
+    std::vector<Layer> layers;
+    std::vector<Buffer> bufs;
+    std::vector<Op> ops;
+    View heads[3];
+    // workspace layout
+    size_t act_bytes = 0, wts_bytes = 0;
+    size_t zero_off = 0, dbox_off = 0, keys_off = 0, counts_off = 0, status_off = 0, scratch_off = 0;
+    uint32_t cand_cap = 0;
+    char* act = nullptr;
+    char* wts = nullptr;
+    bool weights_ready = false;
+};
+
+namespace {
+
+struct Builder {
+    y4_ctx& c;
+    explicit Builder(y4_ctx& ctx) : c(ctx) {}
+
+    View alloc(int side, int ch, bool f32 = false) {
+        Buffer b{side, ch, f32};
+        c.bufs.push_back(b);
+        View v;
+        v.buf = (int)c.bufs.size() - 1; v.side = side; v.cstride = ch; v.coff = 0; v.c = ch;
+        return v;
+    }
+    static View slice(View t, int off, int ch) {
+        View v = t;
+        v.coff = t.coff + off; v.c = ch;
+        return v;
+    }
+    // one conv() unit of the reference; `out` must already have the right shape
+    void conv(View in, View out, int filters, int k, bool down, int act, bool bn = true, const View* res = nullptr,
+              bool upsample = false, bool out_f32 = false) {
+        Layer L{};
+        const int idx = (int)c.layers.size();
+        L.d.idx = idx; L.d.ksize = k; L.d.stride = down ? 2 : 1; L.d.cin = in.c; L.d.cout = filters;
+        L.d.act = act; L.d.has_bn = bn ? 1 : 0; L.d.in_side = in.side; L.d.out_side = down ? in.side / 2 : in.side;
+        L.d.weight_offset = c.weight_floats;
+        c.weight_floats += (bn ? 4 : 1) * (int64_t)filters + (int64_t)filters * in.c * k * k;
+        c.flops_per_image += 2ll * k * k * in.c * filters * L.d.out_side * L.d.out_side;
+        L.cout_pad = (int)round_up(filters, COUT_PAD);
+        c.layers.push_back(L);
+        Op op{};
+        op.kind = idx == 0 ? OP_STEM : OP_CONV;
+        op.conv = idx; op.in = in; op.out = out; op.upsample = upsample; op.out_f32 = out_f32;
+        if (res) { op.res = *res; op.has_res = true; }
+        snprintf(op.name, sizeof(op.name), "c%d", idx);
+        c.ops.push_back(op);
+    }
+    View conv_new(View in, int filters, int k, bool down, int act) {
+        View out = alloc(down ? in.side / 2 : in.side, filters);
+        conv(in, out, filters, k, down, act);
+        return out;
+    }
+    // csp_block (reference custom_layers.py:47-69): returns the [x, route] concat buffer
+    View csp(View din, int width, int repeat, bool bottleneck) {
+        View cat = alloc(din.side, 2 * width);
+        conv(din, slice(cat, width, width), width, 1, false, Y4_ACT_MISH);          // route (created first)
+        View x = conv_new(din, width, 1, false, Y4_ACT_MISH);                        // main-in
+        for (int r = 0; r < repeat; ++r) {                                           // residual_block :34-44
+            View t = conv_new(x, bottleneck ? width / 2 : width, 1, false, Y4_ACT_MISH);
+            View x2 = alloc(din.side, width);
+            conv(t, x2, width, 3, false, Y4_ACT_MISH, true, &x);                     // 3x3 + Add
+            x = x2;
+        }
+        conv(x, slice(cat, 0, width), width, 1, false, Y4_ACT_MISH);                 // main-out
+        return cat;
+    }
+    // the 5-conv PANet run (1x1, 3x3, 1x1, 3x3, 1x1); the last 1x1 writes into `last_out`
+    View five(View x, int narrow, View last_out) {
+        const int L = Y4_ACT_LEAKY;
+        x = conv_new(x, narrow, 1, false, L);
+        x = conv_new(x, narrow * 2, 3, false, L);
+        x = conv_new(x, narrow, 1, false, L);
+        x = conv_new(x, narrow * 2, 3, false, L);
+        conv(x, last_out, narrow, 1, false, L);
+        return last_out;
+    }
+
+    void build() {
+        const int S = c.S, M = Y4_ACT_MISH, L = Y4_ACT_LEAKY;
+        const int nout = 3 * (c.cfg.num_classes + 5);
+        View img; img.buf = -1; img.side = S; img.cstride = 3; img.coff = 0; img.c = 3;     // caller's images
+        // ---- cspdarknet53, reference custom_layers.py:100-138
+        View x = conv_new(img, 32, 3, false, L);                 // c0  (leaky, as the reference)
+        x = conv_new(x, 64, 3, true, L);                         // c1  (leaky, as the reference)
+        x = csp(x, 64, 1, true);
+        x = conv_new(x, 64, 1, false, M);
+        x = conv_new(x, 128, 3, true, M);
+        x = csp(x, 64, 2, false);
+        x = conv_new(x, 128, 1, false, M);
+        x = conv_new(x, 256, 3, true, M);
+        x = csp(x, 128, 8, false);
+        View route0 = x = conv_new(x, 256, 1, false, M);         // c37
+        x = conv_new(x, 512, 3, true, M);
+        x = csp(x, 256, 8, false);
+        View route1 = x = conv_new(x, 512, 1, false, M);         // c58
+        x = conv_new(x, 1024, 3, true, M);
+        x = csp(x, 512, 4, false);
+        x = conv_new(x, 1024, 1, false, M);                      // c71
+        x = conv_new(x, 512, 1, false, L);
+        x = conv_new(x, 1024, 3, false, L);
+        View cat_spp = alloc(x.side, 2048);                      // [mp13 | mp9 | mp5 | x]
+        conv(x, slice(cat_spp, 1536, 512), 512, 1, false, L);    // c74
+        {
+            Op op{};
+            op.kind = OP_SPP; op.in = cat_spp; op.out = cat_spp;
+            snprintf(op.name, sizeof(op.name), "spp");
+            c.ops.push_back(op);
+        }
+        x = conv_new(cat_spp, 512, 1, false, L);
+        x = conv_new(x, 1024, 3, false, L);
+        View cat_bu2 = alloc(x.side, 1024);                      // [down(route1'') | route2]
+        View route2 = slice(cat_bu2, 512, 512);
+        conv(x, route2, 512, 1, false, L);                       // c77
+        // ---- yolov4_neck, reference custom_layers.py:141-198
+        View cat_td1 = alloc(route1.side, 512);                  // [lateral(route1) | up(route2)]
+        conv(route2, slice(cat_td1, 256, 256), 256, 1, false, L, true, nullptr, /*upsample=*/true);   // c78
+        conv(route1, slice(cat_td1, 0, 256), 256, 1, false, L);                                       // c79
+        View cat_bu1 = alloc(route1.side, 512);                  // [down(route0') | route1']
+        View route1p = five(cat_td1, 256, slice(cat_bu1, 256, 256));                                  // c80-c84
+        View cat_td0 = alloc(route0.side, 256);                  // [lateral(route0) | up(route1')]
+        conv(route1p, slice(cat_td0, 128, 128), 128, 1, false, L, true, nullptr, /*upsample=*/true);  // c85
+        conv(route0, slice(cat_td0, 0, 128), 128, 1, false, L);                                       // c86
+        View route0p = five(cat_td0, 128, alloc(route0.side, 128));                                   // c87-c91
+        x = conv_new(route0p, 256, 3, false, L);                                                      // c92
+        c.heads[0] = alloc(route0.side, c.hcs, true); c.heads[0].c = nout;
+        conv(x, c.heads[0], nout, 1, false, Y4_ACT_LINEAR, false, nullptr, false, true);              // c93
+        conv(route0p, slice(cat_bu1, 0, 256), 256, 3, true, L);                                       // c94
+        View route1pp = five(cat_bu1, 256, alloc(route1.side, 256));                                  // c95-c99
+        x = conv_new(route1pp, 512, 3, false, L);                                                     // c100
+        c.heads[1] = alloc(route1.side, c.hcs, true); c.heads[1].c = nout;
+        conv(x, c.heads[1], nout, 1, false, Y4_ACT_LINEAR, false, nullptr, false, true);              // c101
+        conv(route1pp, slice(cat_bu2, 0, 512), 512, 3, true, L);                                      // c102
+        x = five(cat_bu2, 512, alloc(cat_bu2.side, 512));                                             // c103-c107
+        x = conv_new(x, 1024, 3, false, L);                                                           // c108
+        c.heads[2] = alloc(cat_bu2.side, c.hcs, true); c.heads[2].c = nout;
+        conv(x, c.heads[2], nout, 1, false, Y4_ACT_LINEAR, false, nullptr, false, true);              // c109
+    }
+};
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+void layout(y4_ctx& c) {
+    // ---- activations
+    size_t off = 0;
+    c.zero_off = off; off += ZERO_PAGE_BYTES;
+    const size_t nb = (size_t)c.cfg.max_batch;
+    for (auto& b : c.bufs) {
+        b.bytes = nb * b.side * b.side * b.channels * (b.f32 ? 4 : c.es);
+        b.offset = off;
+        off = align256(off + b.bytes);
+    }
+    c.dbox_off = off; off = align256(off + nb * c.nbox * 16);
+    c.cand_cap = (uint32_t)c.nbox * (uint32_t)c.cfg.num_classes;         // worst case: exact for any input
+    c.keys_off = off; off = align256(off + nb * (size_t)c.cand_cap * 8);
+    c.counts_off = off; off = align256(off + nb * 4);
+    c.status_off = off; off = align256(off + 256);
+    c.scratch_off = off; off = align256(off + nb * (size_t)c.cfg.max_total * 28 + nb * 4);
+    c.act_bytes = off;
+    // ---- weights
+    off = 0;
+    for (auto& L : c.layers) {
+        const size_t wbytes = L.d.idx == 0 ? (size_t)L.d.cout * 27 * 4
+                                           : (size_t)L.cout_pad * L.d.ksize * L.d.ksize * L.d.cin * c.es;
+        L.w_off = off; off = align256(off + wbytes);
+        L.scale_off = off; off = align256(off + (size_t)L.cout_pad * 4);
+        L.shift_off = off; off = align256(off + (size_t)L.cout_pad * 4);
+    }
+    c.wts_bytes = off;
+}
+
+int check_handle(y4_handle h) {
+    Y4_REQUIRE(h != nullptr, Y4_EINVAL, "null handle");
+    return Y4_OK;
+}
+int check_ready(y4_handle h, int n) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(h->act && h->wts, Y4_ESTATE, "workspace not bound (call y4_bind_workspace first)");
+    Y4_REQUIRE(h->weights_ready, Y4_ESTATE, "weights not packed (call y4_pack_weights first)");
+    Y4_REQUIRE(n >= 1 && n <= h->cfg.max_batch, Y4_EINVAL, "batch %d outside [1, max_batch=%d]", n, h->cfg.max_batch);
+    return Y4_OK;
+}
+
+char* buf_ptr(y4_handle h, const View& v) { return h->act + h->bufs[v.buf].offset; }
+
+int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s) {
+    if (op.kind == OP_SPP) return spp_launch(h->cfg.dtype, buf_ptr(h, op.in), n, op.in.side, op.in.cstride / 4, s);
+    const Layer& L = h->layers[op.conv];
+    const float* scale = (const float*)(h->wts + L.scale_off);
+    const float* shift = (const float*)(h->wts + L.shift_off);
+    if (op.kind == OP_STEM)
+        return stem_conv_launch(h->cfg.dtype, imgs, n, h->S, h->S, (const float*)(h->wts + L.w_off), scale, shift,
+                                L.d.cout, L.d.act, buf_ptr(h, op.out), op.out.cstride, op.out.coff, s);
+    y4_conv_desc d{};
+    d.dtype = h->cfg.dtype;
+    d.n = n; d.h = op.in.side; d.w = op.in.side; d.cin = op.in.c;
+    d.cout = L.d.cout; d.ksize = L.d.ksize; d.stride = L.d.stride; d.act = L.d.act;
+    d.upsample = op.upsample ? 1 : 0; d.out_f32 = op.out_f32 ? 1 : 0;
+    d.in_cstride = op.in.cstride; d.in_coff = op.in.coff;
+    d.out_cstride = op.out.cstride; d.out_coff = op.out.coff;
+    d.in = buf_ptr(h, op.in); d.wt = h->wts + L.w_off; d.scale = scale; d.shift = shift;
+    d.out = buf_ptr(h, op.out);
+    if (op.has_res) { d.res = buf_ptr(h, op.res); d.res_cstride = op.res.cstride; d.res_coff = op.res.coff; }
+    d.tile = 0;
+    return conv2d_launch(&d, h->act + h->zero_off, s);
+}
+
+int run_decode_nms(y4_handle h, int n, float iou_thr, float score_thr, float* boxes, float* scores, float* classes,
+                   int32_t* valid, int32_t* kept_idx, hipStream_t s, int stage /*0 both, 1 decode, 2 nms*/) {
+    const y4_config& cfg = h->cfg;
+    if (stage != 2) {
+        DecodeK k{};
+        int off = 0, cells = 0;
+        for (int i = 0; i < 3; ++i) {
+            k.head[i] = (const float*)buf_ptr(h, h->heads[i]);
+            k.g[i] = h->heads[i].side; k.stride[i] = cfg.strides[i]; k.box_off[i] = off;
+            off += 3 * k.g[i] * k.g[i]; cells += k.g[i] * k.g[i];
+            k.xyscale[i] = cfg.xyscale[i];
+            k.xyoff[i] = (float)(0.5 * ((double)cfg.xyscale[i] - 1.0));
+        }
+        memcpy(k.anchors, cfg.anchors, sizeof(k.anchors));
+        k.cells_per_img = cells; k.N = n; k.C = cfg.num_classes; k.hcs = h->hcs; k.nbox = h->nbox;
+        k.img_size = (float)cfg.img_size; k.score_thr = score_thr;
+        k.dboxes = (float*)(h->act + h->dbox_off);
+        k.keys = (unsigned long long*)(h->act + h->keys_off);
+        k.counts = (uint32_t*)(h->act + h->counts_off);
+        k.cap = h->cand_cap;
+        if (int r = decode_launch(k, s)) return r;
+    }
+    if (stage != 1) {
+        NmsK k{};
+        k.dboxes = (const float*)(h->act + h->dbox_off);
+        k.keys = (const unsigned long long*)(h->act + h->keys_off);
+        k.counts = (const uint32_t*)(h->act + h->counts_off);
+        k.cap = h->cand_cap; k.N = n; k.C = cfg.num_classes; k.nbox = h->nbox;
+        k.max_total = cfg.max_total; k.max_per_class = cfg.max_per_class; k.iou_thr = iou_thr;
+        k.out_boxes = boxes; k.out_scores = scores; k.out_classes = classes; k.out_valid = valid; k.out_idx = kept_idx;
+        k.status = (uint32_t*)(h->act + h->status_off);
+        if (int r = nms_launch(k, s)) return r;
+    }
+    return Y4_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* y4_last_error(void) { return g_err; }
+const char* y4_version(void) { return "yolo4hip 0.1 (gfx950)"; }
+
+int y4_create(const y4_config* cfg, y4_handle* out) {
+    Y4_REQUIRE(cfg && out, Y4_EINVAL, "y4_create: null argument");
+    // the reference's asserts (models.py:23-24,38); non-square inputs are 'not support yet' there too
+    Y4_REQUIRE(cfg->img_size > 0 && cfg->img_size % 32 == 0, Y4_EINVAL,
+               "img_size %d must be a positive multiple of the last stride (32)", cfg->img_size);
+    Y4_REQUIRE(cfg->num_classes > 0, Y4_EINVAL, "no classes detected!");
+    Y4_REQUIRE(cfg->num_classes <= 4096, Y4_EINVAL, "num_classes %d too large", cfg->num_classes);
+    Y4_REQUIRE(cfg->max_batch >= 1, Y4_EINVAL, "max_batch %d", cfg->max_batch);
+    Y4_REQUIRE(cfg->dtype >= Y4_F32 && cfg->dtype <= Y4_F16, Y4_EINVAL, "dtype %d", cfg->dtype);
+    Y4_REQUIRE(cfg->strides[0] == 8 && cfg->strides[1] == 16 && cfg->strides[2] == 32, Y4_EINVAL,
+               "strides must be 8,16,32 (they are fixed by the graph)");
+    Y4_REQUIRE(cfg->max_total >= 1 && cfg->max_total <= 1024 && cfg->max_per_class >= 1, Y4_EINVAL, "max_total/max_per_class");
+    y4_ctx* c = new y4_ctx();
+    c->cfg = *cfg;
+    c->es = elem_size(cfg->dtype);
+    c->S = cfg->img_size;
+    c->hcs = (int)round_up(3 * (cfg->num_classes + 5), 8);
+    c->nbox = 0;
+    for (int i = 0; i < 3; ++i) { const int g = c->S / cfg->strides[i]; c->nbox += 3 * g * g; }
+    if ((int64_t)c->nbox * cfg->num_classes >= (1ll << 32)) {
+        delete c;
+        set_error("num_boxes*num_classes overflows the 32-bit candidate id");
+        return Y4_EINVAL;
+    }
+    Builder(*c).build();
+    layout(*c);
+    *out = c;
+    return Y4_OK;
+}
+
+int y4_destroy(y4_handle h) {
+    delete h;
+    return Y4_OK;
+}
+
+int y4_num_layers(y4_handle h) { return h ? (int)h->layers.size() : Y4_EINVAL; }
+
+int y4_layer_info(y4_handle h, int idx, y4_layer_desc* out) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(out && idx >= 0 && idx < (int)h->layers.size(), Y4_EINVAL, "layer index %d", idx);
+    *out = h->layers[idx].d;
+    return Y4_OK;
+}
+
+int y4_model_info(y4_handle h, int64_t* flops_per_image, int32_t* num_boxes, int32_t* head_cstride, int64_t* weight_floats) {
+    if (int r = check_handle(h)) return r;
+    if (flops_per_image) *flops_per_image = h->flops_per_image;
+    if (num_boxes) *num_boxes = h->nbox;
+    if (head_cstride) *head_cstride = h->hcs;
+    if (weight_floats) *weight_floats = h->weight_floats;
+    return Y4_OK;
+}
+
+int y4_workspace_bytes(y4_handle h, size_t* act_bytes, size_t* wts_bytes) {
+    if (int r = check_handle(h)) return r;
+    if (act_bytes) *act_bytes = h->act_bytes;
+    if (wts_bytes) *wts_bytes = h->wts_bytes;
+    return Y4_OK;
+}
+
+int y4_bind_workspace(y4_handle h, void* act_dev, size_t act_bytes, void* wts_dev, size_t wts_bytes) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(act_dev && wts_dev, Y4_EINVAL, "y4_bind_workspace: null workspace");
+    Y4_REQUIRE(((uintptr_t)act_dev & 255) == 0 && ((uintptr_t)wts_dev & 255) == 0, Y4_EINVAL, "workspaces must be 256-byte aligned");
+    Y4_REQUIRE(act_bytes >= h->act_bytes, Y4_ENOMEM, "act workspace %zu < %zu bytes", act_bytes, h->act_bytes);
+    Y4_REQUIRE(wts_bytes >= h->wts_bytes, Y4_ENOMEM, "wts workspace %zu < %zu bytes", wts_bytes, h->wts_bytes);
+    h->act = (char*)act_dev;
+    h->wts = (char*)wts_dev;
+    h->weights_ready = false;
+    Y4_CHECK_HIP(hipMemset(h->act + h->zero_off, 0, ZERO_PAGE_BYTES));
+    Y4_CHECK_HIP(hipMemset(h->act + h->status_off, 0, 256));
+    return Y4_OK;
+}
+
+int y4_pack_weights(y4_handle h, const float* blob, size_t n_floats, void* stream) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(h->act && h->wts, Y4_ESTATE, "workspace not bound (call y4_bind_workspace first)");
+    Y4_REQUIRE(blob, Y4_EINVAL, "y4_pack_weights: null blob");
+    Y4_REQUIRE((int64_t)n_floats >= h->weight_floats, Y4_EINVAL, "weight blob has %zu floats, the plan needs %lld",
+               n_floats, (long long)h->weight_floats);
+    hipStream_t s = (hipStream_t)stream;
+    for (const Layer& L : h->layers) {
+        const float* rec = blob + L.d.weight_offset;
+        const float* w = rec + (L.d.has_bn ? 4 : 1) * (int64_t)L.d.cout;
+        if (int r = fold_bn_launch(rec, (float*)(h->wts + L.scale_off), (float*)(h->wts + L.shift_off), L.d.cout,
+                                   L.cout_pad, L.d.has_bn, s))
+            return r;
+        if (L.d.idx == 0) {
+            Y4_CHECK_HIP(hipMemcpyAsync(h->wts + L.w_off, w, (size_t)L.d.cout * 27 * 4, hipMemcpyDeviceToDevice, s));
+        } else {
+            if (int r = pack_conv_weights(h->cfg.dtype, L.d.cout, L.d.cin, L.d.ksize, w, h->wts + L.w_off, s)) return r;
+        }
+    }
+    h->weights_ready = true;
+    return Y4_OK;
+}
+
+int y4_adopt_packed_weights(y4_handle h) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(h->act && h->wts, Y4_ESTATE, "workspace not bound (call y4_bind_workspace first)");
+    h->weights_ready = true;
+    return Y4_OK;
+}
+
+int y4_forward(y4_handle h, const float* imgs, int n, void* stream) {
+    if (int r = check_ready(h, n)) return r;
+    Y4_REQUIRE(imgs, Y4_EINVAL, "y4_forward: null images");
+    for (const Op& op : h->ops)
+        if (int r = run_op(h, op, imgs, n, (hipStream_t)stream)) return r;
+    return Y4_OK;
+}
+
+int y4_get_heads(y4_handle h, int n, float* out_s, float* out_m, float* out_l, void* stream) {
+    if (int r = check_ready(h, n)) return r;
+    float* outs[3] = {out_s, out_m, out_l};
+    for (int i = 0; i < 3; ++i) {
+        if (!outs[i]) continue;
+        const View& v = h->heads[i];
+        if (int r = view_to_f32_launch(Y4_F32, buf_ptr(h, v), outs[i], (int64_t)n * v.side * v.side, v.cstride, v.coff,
+                                       v.c, (hipStream_t)stream))
+            return r;
+    }
+    return Y4_OK;
+}
+
+int y4_set_heads(y4_handle h, int n, const float* in_s, const float* in_m, const float* in_l, void* stream) {
+    if (int r = check_ready(h, n)) return r;
+    const float* ins[3] = {in_s, in_m, in_l};
+    for (int i = 0; i < 3; ++i) {
+        Y4_REQUIRE(ins[i], Y4_EINVAL, "y4_set_heads: null head %d", i);
+        const View& v = h->heads[i];
+        if (int r = f32_to_view_launch(ins[i], (float*)buf_ptr(h, v), (int64_t)n * v.side * v.side, v.cstride, v.c,
+                                       (hipStream_t)stream))
+            return r;
+    }
+    return Y4_OK;
+}
+
+int y4_get_conv_output(y4_handle h, int conv_idx, int n, float* out, size_t out_floats, void* stream) {
+    if (int r = check_ready(h, n)) return r;
+    for (const Op& op : h->ops) {
+        if (op.kind == OP_SPP || op.conv != conv_idx) continue;
+        const View& v = op.out;
+        const int64_t px = (int64_t)n * v.side * v.side;   // for an upsampling conv: the upsampled tensor
+        Y4_REQUIRE((int64_t)out_floats >= px * v.c, Y4_EINVAL, "output buffer too small: %zu < %lld", out_floats,
+                   (long long)(px * v.c));
+        return view_to_f32_launch(op.out_f32 ? Y4_F32 : h->cfg.dtype, buf_ptr(h, v), out, px, v.cstride, v.coff, v.c,
+                                  (hipStream_t)stream);
+    }
+    set_error("no conv with index %d", conv_idx);
+    return Y4_EINVAL;
+}
+
+int y4_decode_nms(y4_handle h, int n, float iou_threshold, float score_threshold, float* boxes, float* scores,
+                  float* classes, int32_t* valid, int32_t* kept_idx, void* stream) {
+    if (int r = check_ready(h, n)) return r;
+    Y4_REQUIRE(boxes && scores && classes && valid, Y4_EINVAL, "y4_decode_nms: null output");
+    const float iou = iou_threshold < 0.f ? h->cfg.iou_threshold : iou_threshold;
+    const float sc = score_threshold < 0.f ? h->cfg.score_threshold : score_threshold;
+    return run_decode_nms(h, n, iou, sc, boxes, scores, classes, valid, kept_idx, (hipStream_t)stream, 0);
+}
+
+int y4_predict(y4_handle h, const float* imgs, int n, float* boxes, float* scores, float* classes, int32_t* valid,
+               int32_t* kept_idx, void* stream) {
+    if (int r = y4_forward(h, imgs, n, stream)) return r;
+    return y4_decode_nms(h, n, -1.f, -1.f, boxes, scores, classes, valid, kept_idx, stream);
+}
+
+int y4_profile(y4_handle h, const float* imgs, int n, float* op_ms, char* names, int cap, int* n_ops, void* stream) {
+    if (int r = check_ready(h, n)) return r;
+    Y4_REQUIRE(imgs && op_ms && n_ops, Y4_EINVAL, "y4_profile: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int total = (int)h->ops.size() + 2;
+    Y4_REQUIRE(cap >= total, Y4_EINVAL, "y4_profile: cap %d < %d ops", cap, total);
+    std::vector<hipEvent_t> ev(total + 1);
+    for (auto& e : ev) Y4_CHECK_HIP(hipEventCreate(&e));
+    // decode/NMS outputs of the profiled run go to the workspace's scratch region
+    float* boxes = (float*)(h->act + h->scratch_off);
+    float* scores = boxes + (size_t)n * h->cfg.max_total * 4;
+    float* classes = scores + (size_t)n * h->cfg.max_total;
+    int32_t* kept = (int32_t*)(classes + (size_t)n * h->cfg.max_total);
+    int32_t* valid = kept + (size_t)n * h->cfg.max_total;
+    int rc = Y4_OK;
+    Y4_CHECK_HIP(hipEventRecord(ev[0], s));
+    int i = 0;
+    for (const Op& op : h->ops) {
+        if ((rc = run_op(h, op, imgs, n, s))) break;
+        if (names) { memset(names + 16 * i, 0, 16); strncpy(names + 16 * i, op.name, 15); }
+        Y4_CHECK_HIP(hipEventRecord(ev[++i], s));
+    }
+    if (!rc) {
+        rc = run_decode_nms(h, n, h->cfg.iou_threshold, h->cfg.score_threshold, boxes, scores, classes, valid, kept, s, 1);
+        if (names) { memset(names + 16 * i, 0, 16); strncpy(names + 16 * i, "decode", 15); }
+        Y4_CHECK_HIP(hipEventRecord(ev[++i], s));
+    }
+    if (!rc) {
+        rc = run_decode_nms(h, n, h->cfg.iou_threshold, h->cfg.score_threshold, boxes, scores, classes, valid, kept, s, 2);
+        if (names) { memset(names + 16 * i, 0, 16); strncpy(names + 16 * i, "nms", 15); }
+        Y4_CHECK_HIP(hipEventRecord(ev[++i], s));
+    }
+    Y4_CHECK_HIP(hipStreamSynchronize(s));
+    if (!rc) {
+        for (int j = 0; j < i; ++j) Y4_CHECK_HIP(hipEventElapsedTime(&op_ms[j], ev[j], ev[j + 1]));
+        *n_ops = i;
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    return rc;
+}
+
+// ---------------------------------------------------------------- standalone operators
+int y4_packed_conv_bytes(int dtype, int cout, int cin, int ksize, int32_t* cout_pad, size_t* bytes) {
+    Y4_REQUIRE(dtype >= Y4_F32 && dtype <= Y4_F16 && cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), Y4_EINVAL,
+               "y4_packed_conv_bytes: bad argument");
+    const int cp = (int)round_up(cout, COUT_PAD);
+    if (cout_pad) *cout_pad = cp;
+    if (bytes) *bytes = (size_t)cp * ksize * ksize * cin * elem_size(dtype);
+    return Y4_OK;
+}
+
+int y4_pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw_dev, void* packed_dev, void* stream) {
+    Y4_REQUIRE(oihw_dev && packed_dev, Y4_EINVAL, "y4_pack_conv_weights: null pointer");
+    return pack_conv_weights(dtype, cout, cin, ksize, oihw_dev, packed_dev, (hipStream_t)stream);
+}
+
+static char* g_zero_page = nullptr;
+int y4_conv2d(const y4_conv_desc* d, void* stream) {
+    if (!g_zero_page) {
+        Y4_CHECK_HIP(hipMalloc((void**)&g_zero_page, ZERO_PAGE_BYTES));
+        Y4_CHECK_HIP(hipMemset(g_zero_page, 0, ZERO_PAGE_BYTES));
+    }
+    return conv2d_launch(d, g_zero_page, (hipStream_t)stream);
+}
+int y4_conv_tile_count(void) { return conv_tile_count(); }
+
+int y4_stem_conv(int dtype, const float* imgs_dev, int n, int h, int w, const float* w_oihw_dev, const float* scale,
+                 const float* shift, int cout, int act, void* out_dev, int out_cstride, int out_coff, void* stream) {
+    return stem_conv_launch(dtype, imgs_dev, n, h, w, w_oihw_dev, scale, shift, cout, act, out_dev, out_cstride,
+                            out_coff, (hipStream_t)stream);
+}
+
+int y4_spp(int dtype, void* buf_dev, int n, int side, int c, void* stream) {
+    return spp_launch(dtype, buf_dev, n, side, c, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+"""`Yolov4` facade: the reference's user API (models.py:17-127, 509-529) over the HIP engine.
+
+Drop-in surface kept: constructor signature and asserts, the attributes users read
+(`class_names, img_size, num_classes, anchors, xyscale, strides, output_sizes, class_color, config,
+weight_path, max_boxes`), `.yolo_model.predict(imgs)` -> 3 raw heads, `.inference_model.predict(imgs)` ->
+`[boxes, scores, classes, valid_detections]`, `.predict / .predict_img / .predict_raw / .predict_nonms`
+with their prints (`img shape:`, `# of bboxes:`) and DataFrame layout.
+Differences, all supersets: the passed `config` is honoured (the reference reads the module global,
+models.py:26-37); grid sizes follow img_size (the reference hard-codes 52/26/13); extra keyword-only
+arguments pick the compute dtype / batch capacity.  Training (`fit`, `training_model`), Keras
+save/load and the mAP tooling are out of scope for this inference framework and raise.
+"""
+import os
+
+import numpy as np
+
+from . import prepost, weights as W
+from .config import yolo_config
+from .engine import Engine
+from .plan import build_plan
+
+
+class _KerasLikeModel:
+    """The slice of `tf.keras.Model` the reference touches: `.predict(x)`."""
+
+    def __init__(self, fn, name):
+        self._fn, self.name = fn, name
+
+    def predict(self, x, batch_size=None, verbose=0, **_):
+        return self._fn(x)
+
+    __call__ = predict
+
+
+class Yolov4(object):
+    def __init__(self, weight_path=None, class_name_path='coco_classes.txt', config=yolo_config, *,
+                 dtype='f32', max_batch=32, synth_seed=0, device=None):
+        assert config['img_size'][0] == config['img_size'][1], 'not support yet'
+        assert config['img_size'][0] % config['strides'][-1] == 0, 'must be a multiple of last stride'
+        self.class_names = [line.strip() for line in open(class_name_path).readlines()]
+        self.img_size = tuple(config['img_size'])
+        self.num_classes = len(self.class_names)
+        self.weight_path = weight_path
+        self.anchors = np.array(config['anchors']).reshape((3, 3, 2))
+        self.xyscale = config['xyscale']
+        self.strides = config['strides']
+        self.output_sizes = [self.img_size[0] // s for s in self.strides]
+        self.class_color = {name: list(np.random.random(size=3) * 255) for name in self.class_names}
+        self.max_boxes = config['max_boxes']
+        self.iou_loss_thresh = config.get('iou_loss_thresh', 0.5)
+        self.config = config
+        assert self.num_classes > 0, 'no classes detected!'
+        self._dtype, self._max_batch, self._synth_seed, self._device = dtype, max_batch, synth_seed, device
+        self.build_model(load_pretrained=True if self.weight_path else False)
+
+    def build_model(self, load_pretrained=True):
+        self.plan = build_plan(self.img_size[0], self.num_classes)
+        self.engine = Engine(self.num_classes, self.config, max_batch=self._max_batch, dtype=self._dtype,
+                             device=self._device)
+        self.yolo_model = _KerasLikeModel(self.engine.forward_heads, 'yolo_model')
+        print(f"nms iou: {self.config['iou_threshold']} score: {self.config['score_threshold']}")
+        self.inference_model = _KerasLikeModel(self.engine.predict, 'inference_model')
+        self.training_model = None      # training is out of scope (inference-only framework)
+        if load_pretrained and self.weight_path and self.weight_path.endswith('.weights'):
+            load_weights(self, self.weight_path)
+            print(f'load from {self.weight_path}')
+        else:
+            # the reference leaves Keras' random initialisation in place; ours is the seeded synthetic set
+            self.engine.load_weight_blob(W.flatten(W.synth_weights(self.plan, self._synth_seed)))
+
+    # ---- out of scope (training / Keras checkpoints)
+    def load_model(self, path):
+        raise NotImplementedError('Keras SavedModel/H5 checkpoints need TensorFlow; load Darknet .weights instead')
+
+    def save_model(self, path):
+        raise NotImplementedError('Keras SavedModel/H5 checkpoints need TensorFlow')
+
+    def fit(self, *a, **k):
+        raise NotImplementedError('training is out of scope of the MI355X inference path')
+
+    # ---- reference models.py:95-98
+    def preprocess_img(self, img):
+        return prepost.preprocess_img(img, self.img_size)
+
+    # ---- reference models.py:109-123 (raw_img: RGB)
+    def predict_img(self, raw_img, random_color=True, plot_img=True, figsize=(10, 10), show_text=True,
+                    return_output=False):
+        print('img shape: ', raw_img.shape)
+        img = self.preprocess_img(raw_img)
+        imgs = np.expand_dims(img, axis=0)
+        pred_output = self.inference_model.predict(imgs)
+        detections = prepost.get_detection_data(img=raw_img, model_outputs=pred_output, class_names=self.class_names)
+        output_img = prepost.draw_bbox(raw_img, detections, cmap=self.class_color, random_color=random_color,
+                                       figsize=figsize, show_text=show_text, show_img=plot_img)
+        if return_output:
+            return output_img, detections
+        return detections
+
+    # ---- reference models.py:125-127
+    def predict(self, img_path, random_color=True, plot_img=True, figsize=(10, 10), show_text=True):
+        raw_img = prepost.imread_rgb(img_path)
+        return self.predict_img(raw_img, random_color, plot_img, figsize, show_text)
+
+    # ---- reference models.py:509-514 (note: no BGR->RGB flip there; cv2.imread order is BGR)
+    def predict_raw(self, img_path):
+        raw_img = prepost.imread_rgb(img_path)[:, :, ::-1]
+        print('img shape: ', raw_img.shape)
+        img = self.preprocess_img(raw_img)
+        imgs = np.expand_dims(img, axis=0)
+        return self.yolo_model.predict(imgs)
+
+    # ---- reference models.py:516-529 (thresholds as run-time arguments)
+    def predict_nonms(self, img_path, iou_threshold=0.413, score_threshold=0.1):
+        raw_img = prepost.imread_rgb(img_path)[:, :, ::-1]
+        print('img shape: ', raw_img.shape)
+        img = self.preprocess_img(raw_img)
+        imgs = np.expand_dims(img, axis=0)
+        print(f'nms iou: {iou_threshold} score: {score_threshold}')
+        pred_output = self.engine.predict(imgs, iou_threshold=iou_threshold, score_threshold=score_threshold)
+        detections = prepost.get_detection_data(img=raw_img, model_outputs=pred_output, class_names=self.class_names)
+        prepost.draw_bbox(raw_img, detections, cmap=self.class_color, random_color=True)
+        return detections
+
+
+def load_weights(model, weights_file_path):
+    """reference utils.py:12-53: read a Darknet `.weights` file into the model.  `model` is a `Yolov4`
+    (the reference passes the Keras `yolo_model`; the facade object owns the engine here)."""
+    ws, _header, unread = W.read_darknet(weights_file_path, model.plan)
+    model.engine.load_weight_blob(W.flatten(ws))
+    if unread == 0:
+        print('all weights read')
+    else:
+        print(f'failed to read  all weights, # of unread weights: {unread}')
+
+
+def default_class_path(name='coco_classes.txt'):
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'class_names', name)

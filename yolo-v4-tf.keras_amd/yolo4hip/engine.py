@@ -1,0 +1,221 @@
+"""Engine: one libyolo4hip handle on one GPU, with its workspaces held as torch-ROCm tensors.
+
+Stands where TensorFlow's runtime stands in the reference: `Yolov4.yolo_model.predict`
+and `Yolov4.inference_model.predict` (reference models.py:113,159,514) end up in `Engine.forward_heads`
+/ `Engine.predict`.  No compute happens in Python and nothing here falls back to a CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import ext
+from .config import yolo_config
+
+
+def _cfg_struct(config, num_classes, max_batch, dtype):
+    c = ext.y4_config()
+    size = config["img_size"]
+    assert size[0] == size[1], "not support yet"                      # reference models.py:23
+    assert size[0] % config["strides"][-1] == 0, "must be a multiple of last stride"   # models.py:24
+    assert num_classes > 0, "no classes detected!"                   # models.py:38
+    c.img_size = int(size[0]); c.num_classes = int(num_classes); c.max_batch = int(max_batch)
+    c.dtype = ext.DTYPE_IDS[dtype] if isinstance(dtype, str) else int(dtype)
+    anchors = np.asarray(config["anchors"], dtype=np.float32).reshape(-1)
+    assert anchors.size == 18, "9 anchors (w,h) expected"
+    for i in range(18):
+        c.anchors[i] = float(anchors[i])
+    for i in range(3):
+        c.xyscale[i] = float(config["xyscale"][i])
+        c.strides[i] = int(config["strides"][i])
+    c.iou_threshold = float(config["iou_threshold"])
+    c.score_threshold = float(config["score_threshold"])
+    c.max_per_class = 100                       # custom_layers.py:293 (hard-coded in the reference)
+    c.max_total = 100                           # custom_layers.py:294
+    return c
+
+
+class Engine:
+    def __init__(self, num_classes, config=None, max_batch=32, dtype="f32", device=None):
+        import torch
+        self.torch = torch
+        self.lib = ext.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("yolo4hip needs a ROCm GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.config = dict(config or yolo_config)
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.num_classes = int(num_classes)
+        self.max_batch = int(max_batch)
+        self.cfg = _cfg_struct(self.config, num_classes, max_batch, dtype)
+        self.dtype = ext.DTYPE_NAMES[self.cfg.dtype]
+        self.img_size = self.cfg.img_size
+        self.handle = C.c_void_p()
+        ext.check(self.lib.y4_create(C.byref(self.cfg), C.byref(self.handle)))
+        flops, nbox, hcs, wfl = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int64()
+        ext.check(self.lib.y4_model_info(self.handle, C.byref(flops), C.byref(nbox), C.byref(hcs), C.byref(wfl)))
+        self.flops_per_image, self.num_boxes = flops.value, nbox.value
+        self.head_cstride, self.weight_floats = hcs.value, wfl.value
+        a, w = C.c_size_t(), C.c_size_t()
+        ext.check(self.lib.y4_workspace_bytes(self.handle, C.byref(a), C.byref(w)))
+        self.act_bytes, self.wts_bytes = a.value, w.value
+        with torch.cuda.device(self.device):
+            self.act = torch.empty(self.act_bytes, dtype=torch.uint8, device=self.device)
+            self.wts = torch.zeros(self.wts_bytes, dtype=torch.uint8, device=self.device)
+            ext.check(self.lib.y4_bind_workspace(self.handle, ext.ptr(self.act), self.act_bytes, ext.ptr(self.wts),
+                                                 self.wts_bytes))
+        self.grids = [self.img_size // s for s in self.config["strides"]]
+        self.nout = 3 * (self.num_classes + 5)
+        self.T = self.cfg.max_total
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self.lib.y4_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- weights
+    def load_weight_blob(self, flat):
+        """flat: float32 Darknet stream (numpy or torch; see weights.flatten / read_darknet)."""
+        torch = self.torch
+        if isinstance(flat, np.ndarray):
+            flat = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float32))
+        flat = flat.to(self.device, dtype=torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            ext.check(self.lib.y4_pack_weights(self.handle, ext.ptr(flat), flat.numel(), ext.stream_ptr()))
+            torch.cuda.current_stream().synchronize()      # `flat` may be freed after this returns
+
+    def adopt_packed(self):
+        ext.check(self.lib.y4_adopt_packed_weights(self.handle))
+
+    def layer_table(self):
+        n = self.lib.y4_num_layers(self.handle)
+        out = []
+        for i in range(n):
+            d = ext.y4_layer_desc()
+            ext.check(self.lib.y4_layer_info(self.handle, i, C.byref(d)))
+            out.append({k: getattr(d, k) for k, _ in ext.y4_layer_desc._fields_})
+        return out
+
+    # ---------------------------------------------------------------- compute
+    def _to_device_images(self, imgs):
+        """array-like [N,H,W,3] any float dtype (Keras casts to float32) -> contiguous cuda float32."""
+        torch = self.torch
+        if isinstance(imgs, torch.Tensor):
+            t = imgs.to(self.device, dtype=torch.float32)
+        else:
+            a = np.asarray(imgs)
+            if a.dtype != np.float32:
+                a = a.astype(np.float32)
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        if t.dim() != 4 or t.shape[1] != self.img_size or t.shape[2] != self.img_size or t.shape[3] != 3:
+            raise ValueError(f"expected images of shape [N,{self.img_size},{self.img_size},3], got {tuple(t.shape)}")
+        return t.contiguous()
+
+    def forward_device(self, imgs_dev):
+        n = imgs_dev.shape[0]
+        with self.torch.cuda.device(self.device):
+            ext.check(self.lib.y4_forward(self.handle, ext.ptr(imgs_dev), n, ext.stream_ptr()))
+
+    def heads_device(self, n):
+        torch = self.torch
+        outs = [torch.empty((n, g, g, self.nout), dtype=torch.float32, device=self.device) for g in self.grids]
+        with torch.cuda.device(self.device):
+            ext.check(self.lib.y4_get_heads(self.handle, n, ext.ptr(outs[0]), ext.ptr(outs[1]), ext.ptr(outs[2]),
+                                            ext.stream_ptr()))
+        return outs
+
+    def set_heads(self, heads):
+        """Load dense float32 raw heads (3 arrays [n,g,g,3(C+5)]) into the workspace (decode/NMS tests)."""
+        torch = self.torch
+        ts = [torch.from_numpy(np.ascontiguousarray(h, dtype=np.float32)).to(self.device) for h in heads]
+        n = ts[0].shape[0]
+        for t, g in zip(ts, self.grids):
+            if tuple(t.shape) != (n, g, g, self.nout):
+                raise ValueError(f"head shape {tuple(t.shape)} != {(n, g, g, self.nout)}")
+        with torch.cuda.device(self.device):
+            ext.check(self.lib.y4_set_heads(self.handle, n, ext.ptr(ts[0]), ext.ptr(ts[1]), ext.ptr(ts[2]),
+                                            ext.stream_ptr()))
+            torch.cuda.current_stream().synchronize()
+        return n
+
+    def alloc_outputs(self, n):
+        torch = self.torch
+        T = self.T
+        return (torch.empty((n, T, 4), dtype=torch.float32, device=self.device),
+                torch.empty((n, T), dtype=torch.float32, device=self.device),
+                torch.empty((n, T), dtype=torch.float32, device=self.device),
+                torch.empty((n,), dtype=torch.int32, device=self.device),
+                torch.empty((n, T), dtype=torch.int32, device=self.device))
+
+    def decode_nms_device(self, n, outs=None, iou_threshold=-1.0, score_threshold=-1.0):
+        outs = outs or self.alloc_outputs(n)
+        b, s, c, v, k = outs
+        with self.torch.cuda.device(self.device):
+            ext.check(self.lib.y4_decode_nms(self.handle, n, float(iou_threshold), float(score_threshold), ext.ptr(b),
+                                             ext.ptr(s), ext.ptr(c), ext.ptr(v), ext.ptr(k), ext.stream_ptr()))
+        return outs
+
+    def predict_device(self, imgs_dev, outs=None):
+        """The whole hot path on device buffers: forward + decode + NMS (async on the current stream)."""
+        n = imgs_dev.shape[0]
+        outs = outs or self.alloc_outputs(n)
+        b, s, c, v, k = outs
+        with self.torch.cuda.device(self.device):
+            ext.check(self.lib.y4_predict(self.handle, ext.ptr(imgs_dev), n, ext.ptr(b), ext.ptr(s), ext.ptr(c),
+                                          ext.ptr(v), ext.ptr(k), ext.stream_ptr()))
+        return outs
+
+    def _chunks(self, imgs):
+        t = self._to_device_images(imgs)
+        for i in range(0, t.shape[0], self.max_batch):     # Keras predict() chunks too (batch_size=32), invisibly
+            yield t[i:i + self.max_batch]
+
+    def forward_heads(self, imgs):
+        """yolo_model.predict(imgs): list of 3 float32 numpy arrays [N,g,g,3(C+5)] (raw logits)."""
+        parts = [[], [], []]
+        for chunk in self._chunks(imgs):
+            self.forward_device(chunk)
+            for i, o in enumerate(self.heads_device(chunk.shape[0])):
+                parts[i].append(o.cpu().numpy())
+        return [np.concatenate(p, axis=0) for p in parts]
+
+    def predict(self, imgs, with_indices=False, iou_threshold=-1.0, score_threshold=-1.0):
+        """inference_model.predict(imgs): [boxes [N,100,4], scores [N,100], classes [N,100], valid [N] int32]
+        as fresh, writable host numpy arrays (the reference's export_prediction mutates them in place,
+        models.py:167-168)."""
+        acc = [[], [], [], [], []]
+        for chunk in self._chunks(imgs):
+            self.forward_device(chunk)
+            outs = self.decode_nms_device(chunk.shape[0], None, iou_threshold, score_threshold)
+            for i, o in enumerate(outs):
+                acc[i].append(o.cpu().numpy())
+        res = [np.concatenate(p, axis=0) for p in acc]
+        return res if with_indices else res[:4]
+
+    def conv_output(self, conv_idx, n):
+        """Dense float32 NHWC copy of conv `conv_idx`'s output from the last forward (parity tap)."""
+        torch = self.torch
+        lt = self.layer_table()[conv_idx]
+        # upsampling convs (78, 85) store the 2x-upsampled tensor
+        side = lt["out_side"] * (2 if conv_idx in (78, 85) else 1)
+        out = torch.empty((n, side, side, lt["cout"]), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            ext.check(self.lib.y4_get_conv_output(self.handle, conv_idx, n, ext.ptr(out), out.numel(), ext.stream_ptr()))
+        return out.cpu().numpy()
+
+    def profile(self, imgs_dev):
+        n = imgs_dev.shape[0]
+        cap = 256
+        ms = (C.c_float * cap)()
+        names = C.create_string_buffer(16 * cap)
+        nops = C.c_int()
+        with self.torch.cuda.device(self.device):
+            ext.check(self.lib.y4_profile(self.handle, ext.ptr(imgs_dev), n, ms, names, cap, C.byref(nops),
+                                          ext.stream_ptr()))
+        raw = names.raw
+        return [(raw[16 * i:16 * i + 16].split(b"\0")[0].decode(), float(ms[i])) for i in range(nops.value)]
