@@ -69,7 +69,10 @@ class _Net:
     def residual_block(self, x, filters1, filters2, activation="leaky"):
         y = self.conv(x, filters1, 1, activation=activation)
         y = self.conv(y, filters2, 3, activation=activation)
-        return x + y
+        out = x + y
+        if (self.i - 1) in self.collect:
+            self.taps[("add", self.i - 1)] = out      # what the HIP path stores for this conv (Add fused)
+        return out
 
     # custom_layers.py:47-69
     def csp_block(self, x, residual_out, repeat, residual_bottleneck=False):
@@ -173,6 +176,7 @@ def yolo_model_forward(imgs_nhwc, weights, num_classes, dtype=torch.float32, col
     assert net.i == len(weights) == 110, net.i
     res = [o.permute(0, 2, 3, 1).contiguous().numpy() for o in outs]
     if collect is not None:
+        # int key: that conv's own output; ('add', idx): output of the residual Add that follows conv idx
         taps = {k: v.permute(0, 2, 3, 1).contiguous().numpy() for k, v in net.taps.items()}
         return res, taps
     return res

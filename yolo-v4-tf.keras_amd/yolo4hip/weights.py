@@ -99,10 +99,10 @@ def write_darknet(path: str, ws: WeightSet, header=(0, 2, 5, 0, 0)):
 
 
 # ----------------------------------------------------------------------------- synthetic weights
-def _gauss_moments(fn):
+def _gauss_moments(fn, mu=0.0):
     z = np.linspace(-8.0, 8.0, 32001)
     pdf = np.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)
-    y = fn(z)
+    y = fn(z + mu)
     dz = z[1] - z[0]
     return float((y * pdf).sum() * dz), float((y * y * pdf).sum() * dz)
 
@@ -115,13 +115,14 @@ def _leaky(z):
     return np.where(z > 0, z, 0.1 * z)
 
 
-_MOMENTS = {ACT_MISH: _gauss_moments(_mish), ACT_LEAKY: _gauss_moments(_leaky), ACT_LINEAR: (0.0, 1.0)}
-# crude second-moment inflation of a stride-1 'same' max-pool over leaky outputs (spatially correlated)
-_POOL_GAIN = {5: 2.5, 9: 3.5, 13: 4.0}
+# crude model of a stride-1 'same' max-pool (spatially correlated inputs): mean shifts up by k std
+_POOL_SHIFT = {5: 1.5, 9: 2.0, 13: 2.3}
 
-HEAD_GAIN = 1.3          # std of class / objectness logits
+RESIDUAL_GAMMA = 0.25
+SYNTH_BETA_MEAN = 1.0     # BN beta mean: keeps most pre-activations in the near-linear region -> well-conditioned net
+HEAD_GAIN = 1.5          # std of class / objectness logits
 HEAD_WH_GAIN = 0.35      # std of tw, th  (exp(0.35 z): boxes within ~0.4x..2.5x of the anchor)
-HEAD_OBJ_BIAS = -3.4
+HEAD_OBJ_BIAS = -2.8
 
 
 def head_cls_bias(num_classes: int) -> float:
@@ -133,6 +134,13 @@ def synth_weights(plan: Plan, seed: int = 0) -> WeightSet:
     mean = {"input": 0.5}
     m2 = {"input": 1.0 / 3.0}     # U[0,1) input
     ws: List[Optional[ConvWeights]] = [None] * len(plan.convs)
+    # convs whose output is the branch operand of a residual Add get a small BN gamma (the usual
+    # "zero-init residual" practice): with gamma 1 each of the 23 blocks x + f(x) amplifies any
+    # perturbation ~1.4x, which makes a RANDOM network chaotic (fp32 rounding noise grows ~10^3 through
+    # the stack, for the CPU oracle and the HIP path alike) -- unlike a trained one.
+    moments = {ACT_MISH: _gauss_moments(_mish, SYNTH_BETA_MEAN), ACT_LEAKY: _gauss_moments(_leaky, SYNTH_BETA_MEAN),
+               ACT_LINEAR: (0.0, 1.0)}
+    branch_convs = {int(op.srcs[1][1:]) for op in plan.ops if op.kind == "add"}
     for op in plan.ops:
         if op.kind == "conv":
             c = plan.convs[op.conv]
@@ -147,8 +155,8 @@ def synth_weights(plan: Plan, seed: int = 0) -> WeightSet:
             if c.bn:
                 w *= np.float32(std)
                 bn = np.zeros((4, c.cout), np.float32)
-                bn[0] = rng.standard_normal(c.cout, dtype=np.float32) * np.float32(0.1)   # beta
-                bn[1] = 1.0                                                               # gamma
+                bn[0] = rng.standard_normal(c.cout, dtype=np.float32) * np.float32(0.1) + np.float32(SYNTH_BETA_MEAN)  # beta
+                bn[1] = RESIDUAL_GAMMA if c.idx in branch_convs else 1.0                  # gamma
                 bn[2] = 0.0                                                               # mean
                 bn[3] = 1.0                                                               # var
                 ws[c.idx] = ConvWeights(w=w, bn=bn)
@@ -161,7 +169,10 @@ def synth_weights(plan: Plan, seed: int = 0) -> WeightSet:
                                 np.where(field_of > 4, head_cls_bias(plan.num_classes), 0.0)).astype(np.float32)
                 bias += rng.standard_normal(c.cout, dtype=np.float32) * np.float32(0.05)
                 ws[c.idx] = ConvWeights(w=w, bias=bias.astype(np.float32))
-            mean[op.dst], m2[op.dst] = _MOMENTS[c.act]
+            mean[op.dst], m2[op.dst] = moments[c.act]
+            if c.idx in branch_convs:
+                mean[op.dst] *= RESIDUAL_GAMMA
+                m2[op.dst] *= RESIDUAL_GAMMA ** 2
         elif op.kind == "add":
             a, b = op.srcs
             mean[op.dst] = mean[a] + mean[b]
@@ -172,8 +183,9 @@ def synth_weights(plan: Plan, seed: int = 0) -> WeightSet:
             m2[op.dst] = sum(m2[s] * plan.chans[s] for s in op.srcs) / tot
         elif op.kind == "maxpool":
             s = op.srcs[0]
-            mean[op.dst] = mean[s] + math.sqrt(m2[s]) * 1.2
-            m2[op.dst] = m2[s] * _POOL_GAIN.get(op.k, 3.0)
+            std_s = math.sqrt(max(m2[s] - mean[s] ** 2, 1e-6))
+            mean[op.dst] = mean[s] + _POOL_SHIFT.get(op.k, 2.0) * std_s
+            m2[op.dst] = mean[op.dst] ** 2 + 0.5 * std_s ** 2
         elif op.kind == "upsample":
             s = op.srcs[0]
             mean[op.dst], m2[op.dst] = mean[s], m2[s]
