@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the whole predict() hot path (forward + decode + NMS) at
+608x608, 80 classes, batch 32 per GPU, bf16 storage / fp32 accumulate, synthetic data.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A step = one y4_predict over one batch of 32 images already resident in HBM (float32 NHWC in [0,1]; the
+PCIe-inclusive rate is noted in DESIGN.md, it is never `value`).  Timed region: barrier +
+torch.cuda.synchronize() on both sides, MAX over ranks, whole-job images / time.
+`roofline` is for the dominant kernel family (conv_igemm_kernel, convs 1..109): algorithmic conv FLOPs of
+one step / its summed per-launch device time, measured with HIP events recorded on the launch stream
+inside the timed region (y4_timing_begin/end).  `cpu_baseline` times the oracle (a torch-CPU/NumPy
+restatement; the reference's tf.keras path cannot run here) on a bounded sample on rank 0 at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "yolo-v4-tf.keras_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(size, ncls, ws, cfg, sample_n=2, runs=2):
+    """Oracle (kind 'port') on the host cores: forward + decode + NMS of `sample_n` images."""
+    import numpy as np
+    import torch
+    from yolo4hip import weights as W
+    from oracle import forward as OF, decode_nms as OD
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    imgs = W.synth_images(sample_n, size, seed=0)
+    def once():
+        heads = OF.yolo_model_forward(imgs, ws, ncls)
+        return OD.inference_from_heads(heads, ncls, cfg["anchors"], cfg["xyscale"], size)
+    once()                                    # warm-up (oneDNN primitive creation, page-in)
+    t0 = time.perf_counter()
+    for _ in range(runs):
+        once()
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_n * runs / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{runs} runs x {sample_n} images {size}x{size}x3, {ncls} classes, fp32 torch-CPU(oneDNN) forward "
+                      f"+ NumPy decode/NMS (oracle/), after 1 warm-up run; {dt:.1f} s of CPU work"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=608)
+    ap.add_argument("--classes", type=int, default=80)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-op", action="store_true", help="also print the per-op time table to stderr")
+    args = ap.parse_args()
+
+    import torch
+    from yolo4hip import dist as D, weights as W
+    from yolo4hip.config import make_config
+    from yolo4hip.engine import Engine
+    from yolo4hip.plan import build_plan
+
+    rank, local_rank, world = D.init_process_group()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    torch.cuda.set_device(local_rank)
+    cfg = make_config(args.size)
+    plan = build_plan(args.size, args.classes)
+    eng = Engine(args.classes, cfg, max_batch=args.batch, dtype=args.dtype, device=f"cuda:{local_rank}")
+    ws_holder = {}
+
+    def make_flat():
+        ws_holder["ws"] = W.synth_weights(plan, seed=0)
+        return W.flatten(ws_holder["ws"])
+
+    D.load_weights_distributed(eng, make_flat, src=0)          # rank 0 packs, RCCL broadcast of the packed blob
+    lo, hi = D.shard_range(args.batch * world, rank, world)    # this rank's slice of the global batch
+    imgs = torch.from_numpy(W.synth_images(hi - lo, args.size, seed=0, first_index=lo)).to(eng.device)
+    outs = eng.alloc_outputs(hi - lo)
+
+    for _ in range(args.warmup):
+        eng.predict_device(imgs, outs)
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    eng.timing_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.predict_device(imgs, outs)
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    dt = D.max_over_ranks(time.perf_counter() - t0)
+    ops, nrec = eng.timing_end()
+
+    if rank == 0:
+        n_img = args.batch * world * args.steps
+        conv_ms = sum(ms for name, ms in ops if name.startswith("c") and name != "c0")
+        conv_flops = sum(c.flops_per_image for c in plan.convs[1:]) * (hi - lo)
+        launches = sum(1 for name, _ in ops if name.startswith("c") and name != "c0")
+        other = {name: ms for name, ms in ops if not name.startswith("c") or name == "c0"}
+        total_ms = sum(ms for _, ms in ops)
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        line = {
+            "metric": "images/sec end-to-end predict() at 608x608 batch 32; conv MFMA %peak",
+            "value": round(n_img / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"yolov4 predict(): {args.size}x{args.size}x3 float32 images resident in HBM -> "
+                                   f"CSPDarknet53+SPP+PANet forward ({plan.flops_per_image / 1e9:.3f} GFLOP/image) "
+                                   f"-> 3-scale decode ({plan.num_boxes} boxes) -> class-aware NMS (100/image); "
+                                   f"{args.classes} classes, {args.dtype} storage, fp32 accumulate, "
+                                   f"seeded synthetic weights",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "sharding": f"batch split over {world} rank(s), no data-path collective"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "kernel": "conv_igemm_kernel (convs 1..109, %d launches/step)" % launches,
+                         "flops_per_step": conv_flops, "kernel_ms_per_step": round(conv_ms, 4),
+                         "timed_steps": nrec},
+            "breakdown_ms_per_step": {"conv_igemm": round(conv_ms, 4), "stem_c0": round(other.get("c0", 0.0), 4),
+                                      "spp": round(other.get("spp", 0.0), 4),
+                                      "decode": round(other.get("decode", 0.0), 4),
+                                      "nms": round(other.get("nms", 0.0), 4), "sum_of_ops": round(total_ms, 4),
+                                      "decode_nms_frac": round((other.get("decode", 0.0) + other.get("nms", 0.0)) /
+                                                               max(total_ms, 1e-9), 4)},
+        }
+        if args.per_op:
+            for name, ms in ops:
+                fl = plan.convs[int(name[1:])].flops_per_image * (hi - lo) if name.startswith("c") else 0
+                print(f"{name:8s} {ms:8.4f} ms  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.1f} TFLOP/s", file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            ws = ws_holder.get("ws") or W.synth_weights(plan, seed=0)
+            line["cpu_baseline"] = cpu_baseline(args.size, args.classes, ws, cfg)
+        print(json.dumps(line), flush=True)
+    D.barrier()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

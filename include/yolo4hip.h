@@ -125,6 +125,13 @@ int y4_predict(y4_handle h, const float* imgs_nhwc_dev, int n, float* boxes_dev,
 int y4_profile(y4_handle h, const float* imgs_nhwc_dev, int n, float* op_ms, char* names, int cap,
                int* n_ops, void* stream);
 
+/* Live per-op timing of the calls in between: while a session is open, each y4_predict (up to max_steps of
+ * them) records a HIP event on its stream after every op, without synchronising.  y4_timing_end
+ * synchronises the stream and returns the mean device time per op in ms ('c1'.., 'spp', 'decode', 'nms'). */
+int y4_timing_begin(y4_handle h, int max_steps);
+int y4_timing_end(y4_handle h, float* op_ms_mean, char* names, int cap, int* n_ops, int* steps_recorded,
+                  void* stream);
+
 /* ---- standalone operators (same kernels as the plan uses; for unit tests and other hosts) ---- */
 
 typedef struct y4_conv_desc {
@@ -155,8 +162,10 @@ int y4_pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* o
  * optional UpSampling2D (custom_layers.py:147,159) + concat-slice store (custom_layers.py:68,...). */
 int y4_conv2d(const y4_conv_desc* d, void* stream);
 int y4_conv_tile_count(void);
-/* Stem conv (cin = 3): float32 images -> dtype, weights float32 [cout][3][3][3] (darknet order) */
-int y4_stem_conv(int dtype, const float* imgs_dev, int n, int h, int w, const float* w_oihw_dev,
+/* Stem conv (cin = 3, reference custom_layers.py:101): float32 images -> dtype.  Weights are the float32
+ * table [(ky*3+kx)*3+ci][cout] made by y4_pack_stem_weights from Darknet (cout,3,3,3) order. */
+int y4_pack_stem_weights(const float* w_oihw_dev, float* wk_dev, int cout, void* stream);
+int y4_stem_conv(int dtype, const float* imgs_dev, int n, int h, int w, const float* wk_dev,
                  const float* scale, const float* shift, int cout, int act, void* out_dev, int out_cstride,
                  int out_coff, void* stream);
 /* SPP (custom_layers.py:130-134): x = buf[..., 3c:4c] -> buf[..., 0:c]=maxpool13, [c:2c]=maxpool9,

@@ -10,25 +10,17 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 // ------------------------------------------------------------------------------------------ stem
-// One thread = one output pixel x all COUT(32) channels; weights [27][COUT] broadcast from LDS.
-// HBM-bound by design: reads 12 B/pixel (fp32 RGB), writes COUT*sizeof(T) per pixel, fully coalesced.
+// One thread = one output pixel x all COUT(32) channels.  The 27x32 weights are read with wave-uniform
+// addresses from a [27][COUT] float table, so they arrive as scalar loads (s_load_dwordx16) and feed
+// v_fma as SGPR operands: no LDS, no per-lane weight registers.  HBM-bound by design: reads 12 B/pixel
+// (fp32 RGB, L1-shared between neighbours), writes COUT*sizeof(T) per pixel, fully coalesced.
 template <int DT, int COUT>
-__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ w_oihw,
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ wk,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         typename Elem<DT>::type* __restrict__ out, int N, int H, int W,
                                                         int out_cstride, int out_coff, int act) {
     using E = Elem<DT>;
     using T = typename E::type;
-    __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
-    __shared__ __attribute__((aligned(16))) float ss[2 * COUT];
-    for (int i = threadIdx.x; i < 27 * COUT; i += 256) {
-        // ws[(ky*3+kx)*3 + ci][co]  <-  w[co][ci][ky][kx]
-        const int co = i % COUT, k = i / COUT;
-        const int ci = k % 3, tap = k / 3;
-        ws[i] = w_oihw[(co * 3 + ci) * 9 + tap];
-    }
-    for (int i = threadIdx.x; i < COUT; i += 256) { ss[i] = scale[i]; ss[COUT + i] = shift[i]; }
-    __syncthreads();
     const int64_t total = (int64_t)N * H * W;
     const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (pix >= total) return;
@@ -38,28 +30,25 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     float acc[COUT];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
-#pragma unroll
+#pragma unroll 1
     for (int ky = 0; ky < 3; ++ky) {
         const int yy = y + ky - 1;
+        const bool oky = (unsigned)yy < (unsigned)H;
+        const float* row = img + (((int64_t)n * H + (oky ? yy : 0)) * W) * 3;
+        float v[9];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int xx = x + kx - 1;
-            const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-            const float* ip = img + (((int64_t)n * H + (ok ? yy : 0)) * W + (ok ? xx : 0)) * 3;
+            const bool ok = oky && (unsigned)xx < (unsigned)W;
+            const float* ip = row + (ok ? xx : 0) * 3;
 #pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                const float v = ok ? ip[ci] : 0.f;
-                const float* wk = ws + ((ky * 3 + kx) * 3 + ci) * COUT;
-#pragma unroll
-                for (int c = 0; c < COUT; c += 4) {
-                    const f32x4 w4 = *(const f32x4*)(wk + c);
-                    acc[c] = fmaf(v, w4[0], acc[c]);
-                    acc[c + 1] = fmaf(v, w4[1], acc[c + 1]);
-                    acc[c + 2] = fmaf(v, w4[2], acc[c + 2]);
-                    acc[c + 3] = fmaf(v, w4[3], acc[c + 3]);
-                }
-            }
+            for (int ci = 0; ci < 3; ++ci) v[kx * 3 + ci] = ok ? ip[ci] : 0.f;
         }
+        const float* wrow = wk + ky * 9 * COUT;        // wave-uniform -> scalar loads
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v[j], wrow[j * COUT + c], acc[c]);
     }
     constexpr int EPC = 16 / (int)sizeof(T);
     T* op = out + pix * out_cstride + out_coff;
@@ -69,24 +58,40 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
         u32x4 raw;
         T* ov = (T*)&raw;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) ov[e] = E::st(apply_act<FAST>(acc[c + e] * ss[c + e] + ss[COUT + c + e], act));
+        for (int e = 0; e < EPC; ++e) ov[e] = E::st(apply_act<FAST>(acc[c + e] * scale[c + e] + shift[c + e], act));
         *(u32x4*)(op + c) = raw;
     }
 }
 
-int stem_conv_launch(int dtype, const float* imgs, int n, int h, int w, const float* w_oihw, const float* scale,
+// Darknet (cout,3,3,3) -> [(ky*3+kx)*3+ci][cout] float table for the stem kernel
+__global__ void pack_stem_kernel(const float* __restrict__ w_oihw, float* __restrict__ wk, int cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 27 * cout) return;
+    const int co = i % cout, k = i / cout;
+    const int ci = k % 3, tap = k / 3;
+    wk[i] = w_oihw[(co * 3 + ci) * 9 + tap];
+}
+
+int pack_stem_weights(const float* w_oihw, float* wk, int cout, hipStream_t stream) {
+    Y4_REQUIRE(w_oihw && wk && cout > 0, Y4_EINVAL, "pack_stem_weights: bad argument");
+    hipLaunchKernelGGL(pack_stem_kernel, dim3((27 * cout + 255) / 256), dim3(256), 0, stream, w_oihw, wk, cout);
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+int stem_conv_launch(int dtype, const float* imgs, int n, int h, int w, const float* wk, const float* scale,
                      const float* shift, int cout, int act, void* out, int out_cstride, int out_coff,
                      hipStream_t stream) {
     Y4_REQUIRE(cout == 32, Y4_EINVAL, "stem_conv: cout %d (the plan's stem has 32 filters)", cout);
-    Y4_REQUIRE(imgs && w_oihw && scale && shift && out, Y4_EINVAL, "stem_conv: null pointer");
+    Y4_REQUIRE(imgs && wk && scale && shift && out, Y4_EINVAL, "stem_conv: null pointer");
     const int epc = 16 / elem_size(dtype);
     Y4_REQUIRE(out_cstride % epc == 0 && out_coff % epc == 0, Y4_EINVAL, "stem_conv: output view not 16-byte aligned");
     const int64_t total = (int64_t)n * h * w;
     const int blocks = (int)((total + 255) / 256);
     switch (dtype) {
-        case Y4_F32: hipLaunchKernelGGL((stem_conv_kernel<Y4_F32, 32>), dim3(blocks), dim3(256), 0, stream, imgs, w_oihw, scale, shift, (float*)out, n, h, w, out_cstride, out_coff, act); break;
-        case Y4_BF16: hipLaunchKernelGGL((stem_conv_kernel<Y4_BF16, 32>), dim3(blocks), dim3(256), 0, stream, imgs, w_oihw, scale, shift, (uint16_t*)out, n, h, w, out_cstride, out_coff, act); break;
-        case Y4_F16: hipLaunchKernelGGL((stem_conv_kernel<Y4_F16, 32>), dim3(blocks), dim3(256), 0, stream, imgs, w_oihw, scale, shift, (_Float16*)out, n, h, w, out_cstride, out_coff, act); break;
+        case Y4_F32: hipLaunchKernelGGL((stem_conv_kernel<Y4_F32, 32>), dim3(blocks), dim3(256), 0, stream, imgs, wk, scale, shift, (float*)out, n, h, w, out_cstride, out_coff, act); break;
+        case Y4_BF16: hipLaunchKernelGGL((stem_conv_kernel<Y4_BF16, 32>), dim3(blocks), dim3(256), 0, stream, imgs, wk, scale, shift, (uint16_t*)out, n, h, w, out_cstride, out_coff, act); break;
+        case Y4_F16: hipLaunchKernelGGL((stem_conv_kernel<Y4_F16, 32>), dim3(blocks), dim3(256), 0, stream, imgs, wk, scale, shift, (_Float16*)out, n, h, w, out_cstride, out_coff, act); break;
         default: set_error("stem_conv: bad dtype %d", dtype); return Y4_EINVAL;
     }
     Y4_CHECK_HIP(hipGetLastError());

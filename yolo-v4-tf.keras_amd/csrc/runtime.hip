@@ -71,6 +71,9 @@ struct y4_ctx {
     char* act = nullptr;
     char* wts = nullptr;
     bool weights_ready = false;
+    // timing session (y4_timing_begin/end): per-op HIP events recorded by y4_predict
+    std::vector<hipEvent_t> t_events;
+    int t_max_steps = 0, t_steps = 0, t_per_step = 0;
 };
 
 namespace {
@@ -400,7 +403,7 @@ int y4_pack_weights(y4_handle h, const float* blob, size_t n_floats, void* strea
                                    L.cout_pad, L.d.has_bn, s))
             return r;
         if (L.d.idx == 0) {
-            Y4_CHECK_HIP(hipMemcpyAsync(h->wts + L.w_off, w, (size_t)L.d.cout * 27 * 4, hipMemcpyDeviceToDevice, s));
+            if (int r = pack_stem_weights(w, (float*)(h->wts + L.w_off), L.d.cout, s)) return r;
         } else {
             if (int r = pack_conv_weights(h->cfg.dtype, L.d.cout, L.d.cin, L.d.ksize, w, h->wts + L.w_off, s)) return r;
         }
@@ -474,51 +477,100 @@ int y4_decode_nms(y4_handle h, int n, float iou_threshold, float score_threshold
     return run_decode_nms(h, n, iou, sc, boxes, scores, classes, valid, kept_idx, (hipStream_t)stream, 0);
 }
 
-int y4_predict(y4_handle h, const float* imgs, int n, float* boxes, float* scores, float* classes, int32_t* valid,
-               int32_t* kept_idx, void* stream) {
-    if (int r = y4_forward(h, imgs, n, stream)) return r;
-    return y4_decode_nms(h, n, -1.f, -1.f, boxes, scores, classes, valid, kept_idx, stream);
+// forward + decode + NMS; when `ev` is given, ev[0] is recorded before the first op and ev[i+1] after op i
+static int predict_impl(y4_handle h, const float* imgs, int n, float* boxes, float* scores, float* classes,
+                        int32_t* valid, int32_t* kept_idx, hipStream_t s, hipEvent_t* ev) {
+    if (int r = check_ready(h, n)) return r;
+    Y4_REQUIRE(imgs && boxes && scores && classes && valid, Y4_EINVAL, "y4_predict: null argument");
+    int i = 0;
+    if (ev) Y4_CHECK_HIP(hipEventRecord(ev[0], s));
+    for (const Op& op : h->ops) {
+        if (int r = run_op(h, op, imgs, n, s)) return r;
+        if (ev) Y4_CHECK_HIP(hipEventRecord(ev[++i], s));
+    }
+    for (int stage = 1; stage <= 2; ++stage) {
+        if (int r = run_decode_nms(h, n, h->cfg.iou_threshold, h->cfg.score_threshold, boxes, scores, classes, valid,
+                                   kept_idx, s, stage))
+            return r;
+        if (ev) Y4_CHECK_HIP(hipEventRecord(ev[++i], s));
+    }
+    return Y4_OK;
 }
 
+int y4_predict(y4_handle h, const float* imgs, int n, float* boxes, float* scores, float* classes, int32_t* valid,
+               int32_t* kept_idx, void* stream) {
+    if (int r = check_handle(h)) return r;
+    hipEvent_t* ev = nullptr;
+    if (h->t_max_steps > 0 && h->t_steps < h->t_max_steps) ev = h->t_events.data() + (size_t)h->t_steps * h->t_per_step;
+    const int rc = predict_impl(h, imgs, n, boxes, scores, classes, valid, kept_idx, (hipStream_t)stream, ev);
+    if (ev && rc == Y4_OK) ++h->t_steps;
+    return rc;
+}
+
+int y4_timing_begin(y4_handle h, int max_steps) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(max_steps >= 1 && max_steps <= 4096, Y4_EINVAL, "y4_timing_begin: max_steps %d", max_steps);
+    Y4_REQUIRE(h->t_max_steps == 0, Y4_ESTATE, "a timing session is already open");
+    h->t_per_step = (int)h->ops.size() + 3;
+    h->t_events.resize((size_t)max_steps * h->t_per_step);
+    for (auto& e : h->t_events) Y4_CHECK_HIP(hipEventCreate(&e));
+    h->t_max_steps = max_steps;
+    h->t_steps = 0;
+    return Y4_OK;
+}
+
+int y4_timing_end(y4_handle h, float* op_ms_mean, char* names, int cap, int* n_ops, int* steps, void* stream) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(h->t_max_steps > 0, Y4_ESTATE, "no timing session is open");
+    const int nops = (int)h->ops.size() + 2;
+    int rc = Y4_OK;
+    if (!op_ms_mean || !n_ops || cap < nops) {
+        set_error("y4_timing_end: need room for %d ops", nops);
+        rc = Y4_EINVAL;
+    }
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess && rc == Y4_OK) {
+        set_error("y4_timing_end: stream synchronize failed");
+        rc = Y4_EHIP;
+    }
+    if (rc == Y4_OK) {
+        for (int j = 0; j < nops; ++j) {
+            double acc = 0.0;
+            for (int st = 0; st < h->t_steps; ++st) {
+                float ms = 0.f;
+                hipEvent_t* ev = h->t_events.data() + (size_t)st * h->t_per_step;
+                if (hipEventElapsedTime(&ms, ev[j], ev[j + 1]) != hipSuccess) { rc = Y4_EHIP; set_error("hipEventElapsedTime failed"); }
+                acc += ms;
+            }
+            op_ms_mean[j] = h->t_steps ? (float)(acc / h->t_steps) : 0.f;
+            if (names) {
+                memset(names + 16 * j, 0, 16);
+                const char* nm = j < (int)h->ops.size() ? h->ops[j].name : (j == (int)h->ops.size() ? "decode" : "nms");
+                strncpy(names + 16 * j, nm, 15);
+            }
+        }
+        *n_ops = nops;
+        if (steps) *steps = h->t_steps;
+    }
+    for (auto& e : h->t_events) (void)hipEventDestroy(e);
+    h->t_events.clear();
+    h->t_max_steps = 0;
+    h->t_steps = 0;
+    return rc;
+}
+
+// One forward + decode + NMS with per-op HIP-event timing (synchronises): a one-step timing session.
 int y4_profile(y4_handle h, const float* imgs, int n, float* op_ms, char* names, int cap, int* n_ops, void* stream) {
     if (int r = check_ready(h, n)) return r;
     Y4_REQUIRE(imgs && op_ms && n_ops, Y4_EINVAL, "y4_profile: null argument");
-    hipStream_t s = (hipStream_t)stream;
-    const int total = (int)h->ops.size() + 2;
-    Y4_REQUIRE(cap >= total, Y4_EINVAL, "y4_profile: cap %d < %d ops", cap, total);
-    std::vector<hipEvent_t> ev(total + 1);
-    for (auto& e : ev) Y4_CHECK_HIP(hipEventCreate(&e));
-    // decode/NMS outputs of the profiled run go to the workspace's scratch region
+    if (int r = y4_timing_begin(h, 1)) return r;
     float* boxes = (float*)(h->act + h->scratch_off);
     float* scores = boxes + (size_t)n * h->cfg.max_total * 4;
     float* classes = scores + (size_t)n * h->cfg.max_total;
     int32_t* kept = (int32_t*)(classes + (size_t)n * h->cfg.max_total);
     int32_t* valid = kept + (size_t)n * h->cfg.max_total;
-    int rc = Y4_OK;
-    Y4_CHECK_HIP(hipEventRecord(ev[0], s));
-    int i = 0;
-    for (const Op& op : h->ops) {
-        if ((rc = run_op(h, op, imgs, n, s))) break;
-        if (names) { memset(names + 16 * i, 0, 16); strncpy(names + 16 * i, op.name, 15); }
-        Y4_CHECK_HIP(hipEventRecord(ev[++i], s));
-    }
-    if (!rc) {
-        rc = run_decode_nms(h, n, h->cfg.iou_threshold, h->cfg.score_threshold, boxes, scores, classes, valid, kept, s, 1);
-        if (names) { memset(names + 16 * i, 0, 16); strncpy(names + 16 * i, "decode", 15); }
-        Y4_CHECK_HIP(hipEventRecord(ev[++i], s));
-    }
-    if (!rc) {
-        rc = run_decode_nms(h, n, h->cfg.iou_threshold, h->cfg.score_threshold, boxes, scores, classes, valid, kept, s, 2);
-        if (names) { memset(names + 16 * i, 0, 16); strncpy(names + 16 * i, "nms", 15); }
-        Y4_CHECK_HIP(hipEventRecord(ev[++i], s));
-    }
-    Y4_CHECK_HIP(hipStreamSynchronize(s));
-    if (!rc) {
-        for (int j = 0; j < i; ++j) Y4_CHECK_HIP(hipEventElapsedTime(&op_ms[j], ev[j], ev[j + 1]));
-        *n_ops = i;
-    }
-    for (auto& e : ev) hipEventDestroy(e);
-    return rc;
+    const int rc = y4_predict(h, imgs, n, boxes, scores, classes, valid, kept, stream);
+    const int rc2 = y4_timing_end(h, op_ms, names, cap, n_ops, nullptr, stream);
+    return rc ? rc : rc2;
 }
 
 // ---------------------------------------------------------------- standalone operators
@@ -546,9 +598,13 @@ int y4_conv2d(const y4_conv_desc* d, void* stream) {
 }
 int y4_conv_tile_count(void) { return conv_tile_count(); }
 
-int y4_stem_conv(int dtype, const float* imgs_dev, int n, int h, int w, const float* w_oihw_dev, const float* scale,
+int y4_pack_stem_weights(const float* w_oihw_dev, float* wk_dev, int cout, void* stream) {
+    return pack_stem_weights(w_oihw_dev, wk_dev, cout, (hipStream_t)stream);
+}
+
+int y4_stem_conv(int dtype, const float* imgs_dev, int n, int h, int w, const float* wk_dev, const float* scale,
                  const float* shift, int cout, int act, void* out_dev, int out_cstride, int out_coff, void* stream) {
-    return stem_conv_launch(dtype, imgs_dev, n, h, w, w_oihw_dev, scale, shift, cout, act, out_dev, out_cstride,
+    return stem_conv_launch(dtype, imgs_dev, n, h, w, wk_dev, scale, shift, cout, act, out_dev, out_cstride,
                             out_coff, (hipStream_t)stream);
 }
 

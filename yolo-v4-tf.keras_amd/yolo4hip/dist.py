@@ -1,0 +1,102 @@
+"""Multi-GPU inference: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI).
+
+The reference never shards inference; its only parallelism is `tf.distribute.MirroredStrategy` around
+training (reference models.py:41-44).  The inference analogue: images are independent
+units, so the batch dimension is split across ranks with NO data-path collective.  Collectives:
+  * init : one broadcast of the packed weight workspace from rank 0 (rank 0 reads/generates + packs;
+           the other ranks adopt the bytes) -- a one-off, so the per-link ring bound does not matter;
+  * steady state: none.  `gather_results` (optional) all_gathers the ~77 KB/rank of NMS outputs.
+Everything except the engine calls works on CPU tensors with the gloo backend (tests/test_dist_cpu.py).
+"""
+import os
+
+import numpy as np
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment; (0, 0, 1) when not launched by it."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend=None):
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world = env_world()
+    if world == 1:
+        return rank, local_rank, world
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous block partition of images [0, n_total): rank r gets [lo, hi).  Remainders go to the
+    lowest ranks, so shards differ by at most one image."""
+    base, extra = divmod(n_total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def broadcast_bytes(buf, src=0):
+    """Broadcast a uint8 tensor in place (the packed weight workspace)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(buf, src=src)
+    return buf
+
+
+def load_weights_distributed(engine, make_flat, src=0):
+    """Rank `src` builds the Darknet float stream (`make_flat()`), packs it on its GPU; the packed
+    workspace is broadcast over RCCL; the other ranks adopt it without touching the file system."""
+    import torch
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if multi else 0
+    if rank == src:
+        engine.load_weight_blob(make_flat())
+    if multi:
+        torch.cuda.synchronize()
+        broadcast_bytes(engine.wts, src)
+        if rank != src:
+            engine.adopt_packed()
+        torch.cuda.synchronize()
+
+
+def gather_results(outs, n_total=None):
+    """all_gather per-rank NMS outputs (tensors with the image dimension first, equal shard sizes) and
+    concatenate them in rank order; returns numpy arrays on every rank."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [o.cpu().numpy() if hasattr(o, "cpu") else np.asarray(o) for o in outs]
+    res = []
+    for o in outs:
+        parts = [torch.empty_like(o) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, o.contiguous())
+        cat = torch.cat(parts, dim=0)
+        res.append(cat.cpu().numpy()[:n_total] if n_total is not None else cat.cpu().numpy())
+    return res
+
+
+def max_over_ranks(value):
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

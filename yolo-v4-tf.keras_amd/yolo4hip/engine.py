@@ -208,6 +208,22 @@ class Engine:
             ext.check(self.lib.y4_get_conv_output(self.handle, conv_idx, n, ext.ptr(out), out.numel(), ext.stream_ptr()))
         return out.cpu().numpy()
 
+    def timing_begin(self, max_steps):
+        ext.check(self.lib.y4_timing_begin(self.handle, int(max_steps)))
+
+    def timing_end(self):
+        """-> ([(op name, mean ms)], steps recorded); synchronises the current stream."""
+        cap = 256
+        ms = (C.c_float * cap)()
+        names = C.create_string_buffer(16 * cap)
+        nops, steps = C.c_int(), C.c_int()
+        with self.torch.cuda.device(self.device):
+            ext.check(self.lib.y4_timing_end(self.handle, ms, names, cap, C.byref(nops), C.byref(steps),
+                                             ext.stream_ptr()))
+        raw = names.raw
+        ops = [(raw[16 * i:16 * i + 16].split(b"\0")[0].decode(), float(ms[i])) for i in range(nops.value)]
+        return ops, steps.value
+
     def profile(self, imgs_dev):
         n = imgs_dev.shape[0]
         cap = 256

@@ -68,10 +68,13 @@ SYMBOLS = {
     "y4_decode_nms": (_I, [_VP, _I, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP]),
     "y4_predict": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "y4_profile": (_I, [_VP, _VP, _I, _VP, _VP, _I, C.POINTER(_I), _VP]),
+    "y4_timing_begin": (_I, [_VP, _I]),
+    "y4_timing_end": (_I, [_VP, _VP, _VP, _I, C.POINTER(_I), C.POINTER(_I), _VP]),
     "y4_packed_conv_bytes": (_I, [_I, _I, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
     "y4_pack_conv_weights": (_I, [_I, _I, _I, _I, _VP, _VP, _VP]),
     "y4_conv2d": (_I, [C.POINTER(y4_conv_desc), _VP]),
     "y4_conv_tile_count": (_I, []),
+    "y4_pack_stem_weights": (_I, [_VP, _VP, _I, _VP]),
     "y4_stem_conv": (_I, [_I, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _I, _VP]),
     "y4_spp": (_I, [_I, _VP, _I, _I, _I, _VP]),
 }
