@@ -1,0 +1,54 @@
+"""N > 1 path on CPU: two processes over the gloo backend exercise the same helpers bench.py and the
+multi-GPU host use (weight-workspace broadcast from rank 0, batch sharding, result gather, max-over-ranks)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "yolo-v4-tf.keras_amd"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from yolo4hip import dist as D, weights as W
+    r, lr, w = D.init_process_group(backend="gloo")
+    assert (r, w) == (rank, world)
+    # 1. packed-weight broadcast: rank 0 holds the bytes, the others start from zeros
+    blob = torch.arange(4096, dtype=torch.int32).view(torch.uint8).clone() if rank == 0 else torch.zeros(16384, dtype=torch.uint8)
+    D.broadcast_bytes(blob, src=0)
+    ok_bcast = bool((blob.view(torch.int32) == torch.arange(4096, dtype=torch.int32)).all())
+    # 2. batch sharding: every rank builds ITS slice of the global synthetic batch
+    n_total = 6
+    lo, hi = D.shard_range(n_total, rank, world)
+    mine = W.synth_images(hi - lo, 16, seed=3, first_index=lo)
+    # stand-in for per-image results: [n,4] + valid[n]
+    res = torch.from_numpy(mine.reshape(hi - lo, -1)[:, :4].copy())
+    valid = torch.arange(lo, hi, dtype=torch.int32)
+    g = D.gather_results([res, valid], n_total)
+    full = W.synth_images(n_total, 16, seed=3).reshape(n_total, -1)[:, :4]
+    ok_gather = np.array_equal(g[0], full) and np.array_equal(g[1], np.arange(n_total, dtype=np.int32))
+    mx = D.max_over_ranks(10.0 + rank)
+    D.barrier()
+    ret[rank] = (ok_bcast, ok_gather, mx)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_protocol():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank in range(world):
+        ok_bcast, ok_gather, mx = ret[rank]
+        assert ok_bcast and ok_gather and mx == 11.0

@@ -1,0 +1,120 @@
+"""Host-side logic of the path: Darknet weight I/O (reference utils.py:12-53), synthetic data,
+pre/post-processing (reference models.py:95-98, utils.py:56-78), sharding helpers."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, CLASS_DIR
+
+
+def test_darknet_roundtrip_and_layout(tmp_path):
+    from yolo4hip import weights as W
+    from yolo4hip.plan import build_plan
+    plan = build_plan(64, 3)
+    ws = W.synth_weights(plan, seed=5)
+    path = str(tmp_path / "tiny.weights")
+    W.write_darknet(path, ws)
+    assert os.path.getsize(path) == 20 + 4 * plan.n_params            # 5 x int32 header (utils.py:16)
+    ws2, header, unread = W.read_darknet(path, plan)
+    assert unread == 0 and header.shape == (5,)
+    for a, b in zip(ws, ws2):
+        assert np.array_equal(a.w, b.w)
+        assert (a.bn is None) == (b.bn is None)
+        assert np.array_equal(a.bn if a.bn is not None else a.bias, b.bn if b.bn is not None else b.bias)
+    flat = W.flatten(ws)
+    c0 = plan.convs[0]
+    assert np.array_equal(flat[:c0.cout], ws[0].bn[0])                 # beta first (Darknet row order, utils.py:28)
+    assert np.array_equal(flat[4 * c0.cout:4 * c0.cout + 27], ws[0].w[0].reshape(-1))   # then (out,in,h,w)
+    assert [i for i, cw in enumerate(ws) if cw.bn is None] == [93, 101, 109]
+    with open(path, "ab") as f:
+        np.zeros(3, np.float32).tofile(f)
+    assert W.read_darknet(path, plan)[2] == 3                          # true unread count (reference prints 0)
+    with pytest.raises(ValueError):
+        W.unflatten(plan, flat[:-1])
+
+
+def test_scale_shift_uses_keras_eps():
+    from yolo4hip.weights import ConvWeights
+    bn = np.asarray([[0.5], [2.0], [1.0], [3.0]], np.float32)
+    s, h = ConvWeights(w=np.zeros((1, 1, 1, 1), np.float32), bn=bn).scale_shift()
+    assert abs(s[0] - 2.0 / np.sqrt(3.0 + 1e-3)) < 1e-6 and abs(h[0] - (0.5 - 1.0 * s[0])) < 1e-6
+
+
+def test_synthetic_data_is_deterministic_and_shardable():
+    from yolo4hip import weights as W
+    from yolo4hip.plan import build_plan
+    plan = build_plan(64, 2)
+    a, b = W.synth_weights(plan, 3), W.synth_weights(plan, 3)
+    assert all(np.array_equal(x.w, y.w) for x, y in zip(a, b))
+    assert not np.array_equal(a[5].w, W.synth_weights(plan, 4)[5].w)
+    full = W.synth_images(4, 32, seed=9)
+    assert full.dtype == np.float32 and full.min() >= 0 and full.max() < 1
+    assert np.array_equal(full[2:4], W.synth_images(2, 32, seed=9, first_index=2))
+
+
+def test_shard_range_partitions_everything():
+    from yolo4hip.dist import shard_range
+    for n, world in ((256, 8), (32, 1), (10, 4), (3, 8)):
+        spans = [shard_range(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert shard_range(256, 3, 8) == (96, 128)
+
+
+def test_imread_and_preprocess_street_jpeg():
+    from yolo4hip import prepost
+    img = prepost.imread_rgb(os.path.join(GOLDEN, "street.jpeg"))
+    assert img.shape == (185, 273, 3) and img.dtype == np.uint8       # notebook: 'img shape: (185, 273, 3)'
+    x = prepost.preprocess_img(img, (416, 416, 3))
+    assert x.shape == (416, 416, 3) and x.dtype == np.float64 and 0 <= x.min() and x.max() <= 1
+    with pytest.raises(TypeError):
+        prepost.imread_rgb("/nonexistent/file.jpg")                    # cv2.imread -> None -> TypeError in the reference
+
+
+def test_resize_bilinear_properties():
+    from yolo4hip import prepost
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(prepost.resize_bilinear(img, (53, 37)), img)
+    const = np.full((20, 30, 3), 77, np.uint8)
+    assert np.all(prepost.resize_bilinear(const, (64, 48)) == 77)
+    up = prepost.resize_bilinear(img, (128, 96))
+    ref = prepost._resize_bilinear_float(img.astype(np.float64), 128, 96)
+    assert up.shape == (96, 128, 3) and np.abs(up.astype(np.float64) - ref).max() <= 1.0   # fixed point vs float: 1 LSB
+    ramp = np.tile(np.arange(0, 200, 2, dtype=np.uint8)[None, :, None], (4, 1, 3))
+    r2 = prepost.resize_bilinear(ramp, (200, 4))
+    assert np.all(np.diff(r2[0, :, 0].astype(int)) >= 0)
+
+
+def test_get_detection_data_contract(capsys):
+    from yolo4hip import prepost
+    names = [l.strip() for l in open(os.path.join(CLASS_DIR, "coco_classes.txt"))]
+    assert len(names) == 80 and names[0] == "person" and names[2] == "car"
+    boxes = np.zeros((2, 100, 4), np.float32); scores = np.zeros((2, 100), np.float32)
+    classes = np.zeros((2, 100), np.float32); valid = np.asarray([2, 0], np.int32)
+    boxes[0, 0] = [0.4213, 0.5351, 0.5055, 0.9027]
+    boxes[0, 1] = [0.2088, 0.5243, 0.3040, 0.5676]
+    scores[0, :2] = [0.993157, 0.344773]; classes[0, :2] = [0, 2]
+    img = np.zeros((185, 273, 3), np.uint8)
+    df = prepost.get_detection_data(img, [boxes, scores, classes, valid], names)
+    assert "# of bboxes: 2" in capsys.readouterr().out
+    assert list(df.columns) == ['x1', 'y1', 'x2', 'y2', 'class_name', 'score', 'w', 'h']
+    assert len(df) == 2 and df['x1'].dtype == np.int64
+    r = df.iloc[0]
+    assert (r.x1, r.y1, r.x2, r.y2) == (int(0.4213 * 273), int(0.5351 * 185), int(0.5055 * 273), int(0.9027 * 185))
+    assert (r.w, r.h) == (r.x2 - r.x1, r.y2 - r.y1) and r.class_name == "person"
+    assert df.iloc[1].class_name == "car" and abs(df.iloc[1].score - 0.344773) < 1e-6
+    out = prepost.draw_bbox(img, df, cmap={n: [255, 0, 0] for n in names}, random_color=False, show_img=False)
+    assert out.shape == img.shape and out.sum() > 0
+
+
+def test_config_mirror():
+    from yolo4hip.config import make_config, yolo_config
+    assert yolo_config['img_size'] == (416, 416, 3) and yolo_config['strides'] == [8, 16, 32]
+    assert yolo_config['iou_threshold'] == 0.413 and yolo_config['score_threshold'] == 0.3 and yolo_config['max_boxes'] == 100
+    assert len(yolo_config['anchors']) == 18 and yolo_config['xyscale'] == [1.2, 1.1, 1.05]
+    c = make_config(608)
+    assert c['img_size'] == (608, 608, 3) and yolo_config['img_size'] == (416, 416, 3)

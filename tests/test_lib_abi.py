@@ -1,0 +1,70 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/yolo4hip.h declares, and its
+host-only entry points report errors the documented way (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+from helpers import ROOT
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "yolo4hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(y4_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from yolo4hip import ext
+    lib = ext.load()
+    declared = _header_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in yolo4hip.h but not exported"
+        assert name in ext.SYMBOLS, f"{name} has no ctypes prototype in ext.SYMBOLS"
+    assert sorted(ext.SYMBOLS) == declared
+    assert lib.y4_version().decode().startswith("yolo4hip")
+    assert lib.y4_conv_tile_count() >= 4
+
+
+def test_struct_layouts_match_header_sizes():
+    from yolo4hip import ext
+    assert C.sizeof(ext.y4_config) == 4 * 4 + 18 * 4 + 3 * 4 + 3 * 4 + 2 * 4 + 2 * 4
+    assert C.sizeof(ext.y4_layer_desc) == 9 * 4 + 4 + 8
+    assert C.sizeof(ext.y4_conv_desc) == 17 * 4 + 4 + 6 * 8 + 8     # 17 ints, pad, 6 pointers, tile + pad
+
+
+def test_error_reporting_host_only():
+    from yolo4hip import ext
+    from yolo4hip.config import make_config
+    from yolo4hip.engine import _cfg_struct
+    lib = ext.load()
+    h = C.c_void_p()
+    bad = _cfg_struct(make_config(416), 80, 1, "f32")
+    bad.img_size = 400                               # reference models.py:24 assert
+    assert lib.y4_create(C.byref(bad), C.byref(h)) == -22
+    assert b"multiple" in lib.y4_last_error()
+    bad = _cfg_struct(make_config(416), 80, 1, "f32")
+    bad.num_classes = 0                              # reference models.py:38 assert
+    assert lib.y4_create(C.byref(bad), C.byref(h)) == -22
+    assert b"no classes detected" in lib.y4_last_error()
+    ok = _cfg_struct(make_config(64), 2, 1, "f16")
+    assert lib.y4_create(C.byref(ok), C.byref(h)) == 0
+    a, w = C.c_size_t(), C.c_size_t()
+    assert lib.y4_workspace_bytes(h, C.byref(a), C.byref(w)) == 0 and a.value > 0 and w.value > 0
+    assert lib.y4_forward(h, None, 1, None) == -1    # Y4_ESTATE: workspace not bound
+    assert b"workspace not bound" in lib.y4_last_error()
+    assert lib.y4_bind_workspace(h, None, 0, None, 0) == -22
+    assert lib.y4_layer_info(h, 110, None) == -22
+    assert lib.y4_destroy(h) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from yolo4hip import ext
+    monkeypatch.setattr(ext, "_lib", None)
+    monkeypatch.setattr(ext, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        ext.load()
+    except ImportError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("ext.load() must raise when the shared library is missing")
