@@ -27,13 +27,15 @@ for p in (os.path.join(ROOT, "yolo-v4-tf.keras_amd"), ROOT):
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(size, ncls, ws, cfg, sample_n=2, runs=2):
+def cpu_baseline(size, ncls, ws, cfg, sample_n=8, runs=3):
     """Oracle (kind 'port') on the host cores: forward + decode + NMS of `sample_n` images."""
     import numpy as np
     import torch
     from yolo4hip import weights as W
     from oracle import forward as OF, decode_nms as OD
-    cores = os.cpu_count() or 1
+    # measured on the GPU box's host (2x EPYC 9575F, 256 hardware threads): oneDNN is fastest around 32
+    # threads (3.9 img/s) and collapses when every hardware thread is used (0.02 img/s at 256)
+    cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     imgs = W.synth_images(sample_n, size, seed=0)
     def once():
