@@ -12,6 +12,8 @@ for f in conv_igemm misc_kernels decode_nms runtime; do
     pids+=($!)
   fi
 done
-for p in "${pids[@]}"; do wait $p; done
+for p in "${pids[@]}"; do wait $p || { echo "compile failed"; exit 1; }; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/conv_igemm.o build/misc_kernels.o build/decode_nms.o build/runtime.o
+# every kernel must have its host stub (a target builtin inside a template can silently drop it)
+if nm -D --undefined-only $OUT | grep -q "_ZN2y4"; then echo "error: undefined y4 symbols in $OUT"; nm -D --undefined-only $OUT | grep "_ZN2y4" | head -3; exit 1; fi
 echo "built $OUT"

@@ -37,6 +37,7 @@ struct ConvK {
     int in_cstride, in_coff, out_cstride, out_coff, res_cstride, res_coff;
     int ksize, stride, pad, act, upsample, out_f32;
     int grid_m, grid_n;
+    unsigned in_bytes, wt_bytes;   // buffer-descriptor extents (bounds-checked loads)
 };
 
 template <int CPR> __device__ __forceinline__ int swz(int row) {
@@ -64,12 +65,24 @@ template <> struct Mma<Y4_F16> {
     }
 };
 
-__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// buffer_load_dwordx4 ... lds: 16 bytes per lane from (descriptor base + voffset + soffset) to LDS at
+// (wave-uniform lds_dst + lane*16); lanes whose voffset is outside the descriptor's extent receive zeros.
+// Kept in a NON-template function: inside a template the target builtin is checked at instantiation time
+// for the host pass too, which silently drops the kernel's host stub.
+__device__ __forceinline__ void buffer_load16_lds(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
 
-template <int DT, int BM, int BN, int WM, int WN, int BKB>
+template <int N> __device__ __forceinline__ void wait_vmcnt_then_barrier() {
+    // counted wait for this wave's own LDS-DMA loads, then the workgroup barrier; one asm statement with a
+    // "memory" clobber so that neither the compiler's loads/stores nor its own waitcnt logic move across it
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int ES = (DT == Y4_F32) ? 4 : 2;
@@ -87,6 +100,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
     constexpr int KSTEPS = BKB / 64;        // MFMA k-steps (4 chunks each) per tile
     static_assert(BM % RPI == 0 && (BN % RPI == 0 || (RPI % BN == 0 && (BN * CPR) % 64 == 0)), "tile rows vs rows-per-iteration");
     static_assert(MREP >= 1 && NREP >= 1, "wave tile");
+    constexpr int LPT = A_IT + B_IT;        // LDS-DMA instructions a wave issues per stage
+    static_assert(NST >= 2 && NST <= 4 && (NST == 2 || !B_PART), "deep pipelines need uniform loads per wave");
+    static_assert((NST - 2) * LPT <= 63, "vmcnt field");
     using E = Elem<DT>;
     using T = typename E::type;
 
@@ -106,7 +122,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
 
-    // ---- staging set-up: this thread copies physical chunk slot `q` of rows r0 + j*RPI
+    // ---- staging set-up: this thread copies physical chunk slot `q` of rows r0 + j*RPI.
+    // Loads are buffer_load_dwordx4 ... lds through two raw buffer descriptors (activations, weights): the
+    // per-lane byte offset is fixed per (row, tap), the K-tile advance (c0) rides in the scalar soffset, and a
+    // tap that falls into the padding (or a row past M) gets an out-of-range voffset, which the hardware
+    // bounds check turns into zeros -- no per-tile address arithmetic, no zero page.
     const int q = tid % CPR, r0 = tid / CPR;
     int a_off[A_IT], a_hi[A_IT], a_wi[A_IT];
     const int HoWo = p.Ho * p.Wo;
@@ -118,11 +138,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
         const int n = mm / HoWo, rem = mm - n * HoWo;
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
         const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-        a_off[j] = ((n * p.H + hi0) * p.W + wi0) * p.in_cstride + p.in_coff + ((q ^ swz<CPR>(row)) * EPC);
-        a_hi[j] = m < p.M ? hi0 : -100000;     // rows past M never validate -> zero page
+        a_off[j] = (((n * p.H + hi0) * p.W + wi0) * p.in_cstride + p.in_coff + ((q ^ swz<CPR>(row)) * EPC)) * ES;
+        a_hi[j] = m < p.M ? hi0 : -100000;     // rows past M never validate -> zeros
         a_wi[j] = wi0;
     }
-    const char* b_src[B_IT];
+    int b_off[B_IT];
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
         const int row = B_PART ? (r0 % BN) : (r0 + j * RPI);
@@ -130,31 +150,39 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
         const int wb = row / WCH, pr = row - wb * WCH;
         const int jn = pr >> 4, i = pr & 15, g = i >> 2, r = i & 3;
         const int ch = n0 + wb * WCH + g * CPL + jn * 4 + r;
-        b_src[j] = p.wt + ((int64_t)ch * p.K + ((q ^ swz<CPR>(row)) * EPC)) * ES;
+        b_off[j] = (ch * p.K + ((q ^ swz<CPR>(row)) * EPC)) * ES;
     }
-    char* const lds_a_dst = smem + (wave * 64) * 16;                 // + j*NT*16 (+ lane*16 by hardware)
-    char* const lds_b_dst = smem + BM * BKB + (wave * 64) * 16;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(p.wt, p.wt_bytes);
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);          // provably uniform -> SALU/M0 path
 
-    int ky = 0, kx = 0, c0 = 0;
-    auto stage = [&](int buf) {
-        char* da = lds_a_dst + buf * STAGE;
-        char* db = lds_b_dst + buf * STAGE;
-        const int tap_off = (ky * p.W + kx) * p.in_cstride + c0;
+    int ky = 0, kx = 0, c0b = 0, ktb = 0;          // staging cursor: tap, byte offset of c0, byte offset of k in the weights
+    int a_vo[A_IT];
+    auto set_tap = [&]() {
+        const int tap_off = ((ky * p.W + kx) * p.in_cstride) * ES;
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) {
             const bool ok = (unsigned)(a_hi[j] + ky) < (unsigned)p.H && (unsigned)(a_wi[j] + kx) < (unsigned)p.W;
-            const char* src = ok ? p.in + (int64_t)(a_off[j] + tap_off) * ES : p.zero;
-            glds16(src, da + j * (NT * 16));
+            a_vo[j] = ok ? a_off[j] + tap_off : (int)0x80000000;            // >= num_records -> reads as zero
         }
+    };
+    set_tap();
+    auto stage = [&](int buf) {
+        const int da = buf * STAGE + wave_lds;
+        const int db = da + BM * BKB;
 #pragma unroll
-        for (int j = 0; j < B_IT; ++j) {
-            if (!B_PART || tid < BN * CPR) glds16(b_src[j], db + j * (NT * 16));     // wave-uniform predicate
-            b_src[j] += BKB;
-        }
-        c0 += BK;
-        if (c0 >= p.Cin) {
-            c0 = 0;
+        for (int j = 0; j < A_IT; ++j)
+            buffer_load16_lds(rs_in, smem + da + j * (NT * 16), a_vo[j], c0b);
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j)
+            if (!B_PART || tid < BN * CPR)                                   // wave-uniform predicate
+                buffer_load16_lds(rs_wt, smem + db + j * (NT * 16), b_off[j], ktb);
+        ktb += BKB;
+        c0b += BKB;
+        if (c0b >= p.Cin * ES) {
+            c0b = 0;
             if (++kx >= p.ksize) { kx = 0; ++ky; }
+            set_tap();
         }
     };
 
@@ -172,14 +200,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
 #pragma unroll
         for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // NST-stage ring: tiles kt+1 .. kt+NST-2 stay in flight (counted vmcnt, never drained in steady state)
+    // while tile kt is consumed; ONE barrier per K-tile: it proves tile kt has landed for every wave and
+    // that every wave is done reading the stage (tile kt-1's) that the next stage() call overwrites.
     const int nk = p.K / BK;
-    stage(0);
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) stage(s);
+    int cur = 0, nxt = NST - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // tile kt landed; everyone finished reading the other stage
-        if (kt + 1 < nk) stage((kt + 1) & 1);
-        const char* sx = lds_x + (kt & 1) * STAGE;
-        const char* sw = lds_w + (kt & 1) * STAGE;
+        const int ahead = nk - 1 - kt;         // tiles issued after kt so far (capped at NST-2)
+        if (NST == 2 || ahead == 0) wait_vmcnt_then_barrier<0>();
+        else if (NST == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT>();
+        else wait_vmcnt_then_barrier<2 * LPT>();
+        if (kt + NST - 1 < nk) stage(nxt);
+        const char* sx = lds_x + cur * STAGE;
+        const char* sw = lds_w + cur * STAGE;
+        cur = cur + 1 == NST ? 0 : cur + 1;
+        nxt = nxt + 1 == NST ? 0 : nxt + 1;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             u32x4 xf[MREP], wf[NREP];
@@ -266,30 +304,37 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
 
 // ------------------------------------------------------------------------------------------- launch
 struct TileCfg {
-    int bm, bn, wm, wn, bkb;
+    int bm, bn, wm, wn, bkb, nst;
 };
 // id 1..N; the table is also what tests sweep through y4_conv_desc.tile
 static const TileCfg kTiles[] = {
-    {128, 128, 2, 2, 128},  // 1
-    {128, 128, 2, 2, 64},   // 2
-    {128, 64, 4, 1, 128},   // 3
-    {128, 64, 4, 1, 64},    // 4
-    {128, 32, 4, 1, 128},   // 5
-    {128, 32, 4, 1, 64},    // 6
-    {256, 128, 4, 2, 128},  // 7
-    {256, 128, 4, 2, 64},   // 8
-    {64, 128, 1, 4, 128},   // 9
+    {128, 128, 2, 2, 128, 2},  // 1
+    {128, 128, 2, 2, 64, 2},   // 2
+    {128, 64, 4, 1, 128, 2},   // 3
+    {128, 64, 4, 1, 64, 2},    // 4
+    {128, 32, 4, 1, 128, 2},   // 5
+    {128, 32, 4, 1, 64, 2},    // 6
+    {256, 128, 4, 2, 128, 2},  // 7
+    {256, 128, 4, 2, 64, 2},   // 8
+    {64, 128, 1, 4, 128, 2},   // 9
+    {128, 128, 2, 2, 128, 3},  // 10
+    {128, 128, 2, 2, 128, 4},  // 11
+    {128, 128, 2, 2, 64, 4},   // 12
+    {256, 128, 4, 2, 128, 3},  // 13
+    {64, 128, 1, 4, 128, 4},   // 14
+    {128, 64, 4, 1, 128, 4},   // 15
+    {128, 64, 4, 1, 64, 4},    // 16
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 int conv_tile_count() { return kNumTiles; }
 
-template <int DT, int BM, int BN, int WM, int WN, int BKB>
+template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST>
 static int launch_cfg(const ConvK& k, hipStream_t stream) {
-    constexpr int lds = 2 * (BM + BN) * BKB;
-    auto kern = conv_igemm_kernel<DT, BM, BN, WM, WN, BKB>;
+    constexpr int lds = NST * (BM + BN) * BKB;
+    auto kern = conv_igemm_kernel<DT, BM, BN, WM, WN, BKB, NST>;
     static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
+    if (!attr_set && lds > 48 * 1024) {
         Y4_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
@@ -301,15 +346,22 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
 template <int DT>
 static int launch_dt(int tile, const ConvK& k, hipStream_t s) {
     switch (tile) {
-        case 1: return launch_cfg<DT, 128, 128, 2, 2, 128>(k, s);
-        case 2: return launch_cfg<DT, 128, 128, 2, 2, 64>(k, s);
-        case 3: return launch_cfg<DT, 128, 64, 4, 1, 128>(k, s);
-        case 4: return launch_cfg<DT, 128, 64, 4, 1, 64>(k, s);
-        case 5: return launch_cfg<DT, 128, 32, 4, 1, 128>(k, s);
-        case 6: return launch_cfg<DT, 128, 32, 4, 1, 64>(k, s);
-        case 7: return launch_cfg<DT, 256, 128, 4, 2, 128>(k, s);
-        case 8: return launch_cfg<DT, 256, 128, 4, 2, 64>(k, s);
-        case 9: return launch_cfg<DT, 64, 128, 1, 4, 128>(k, s);
+        case 1: return launch_cfg<DT, 128, 128, 2, 2, 128, 2>(k, s);
+        case 2: return launch_cfg<DT, 128, 128, 2, 2, 64, 2>(k, s);
+        case 3: return launch_cfg<DT, 128, 64, 4, 1, 128, 2>(k, s);
+        case 4: return launch_cfg<DT, 128, 64, 4, 1, 64, 2>(k, s);
+        case 5: return launch_cfg<DT, 128, 32, 4, 1, 128, 2>(k, s);
+        case 6: return launch_cfg<DT, 128, 32, 4, 1, 64, 2>(k, s);
+        case 7: return launch_cfg<DT, 256, 128, 4, 2, 128, 2>(k, s);
+        case 8: return launch_cfg<DT, 256, 128, 4, 2, 64, 2>(k, s);
+        case 9: return launch_cfg<DT, 64, 128, 1, 4, 128, 2>(k, s);
+        case 10: return launch_cfg<DT, 128, 128, 2, 2, 128, 3>(k, s);
+        case 11: return launch_cfg<DT, 128, 128, 2, 2, 128, 4>(k, s);
+        case 12: return launch_cfg<DT, 128, 128, 2, 2, 64, 4>(k, s);
+        case 13: return launch_cfg<DT, 256, 128, 4, 2, 128, 3>(k, s);
+        case 14: return launch_cfg<DT, 64, 128, 1, 4, 128, 4>(k, s);
+        case 15: return launch_cfg<DT, 128, 64, 4, 1, 128, 4>(k, s);
+        case 16: return launch_cfg<DT, 128, 64, 4, 1, 64, 4>(k, s);
     }
     set_error("conv2d: unknown tile id %d", tile);
     return Y4_EINVAL;
@@ -356,7 +408,12 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
     Y4_REQUIRE((int64_t)d->n * k.Ho * k.Wo < (1ll << 31), Y4_EINVAL, "conv2d: too many output pixels");
     k.M = d->n * k.Ho * k.Wo;
     k.K = d->ksize * d->ksize * d->cin;
-    Y4_REQUIRE((int64_t)d->n * d->h * d->w * d->in_cstride < (1ll << 31), Y4_EINVAL, "conv2d: input too large");
+    const int64_t in_bytes = (int64_t)d->n * d->h * d->w * d->in_cstride * es;
+    const int64_t wt_bytes = (int64_t)round_up(d->cout, COUT_PAD) * k.K * es;
+    Y4_REQUIRE(in_bytes < (1ll << 31) && wt_bytes < (1ll << 31), Y4_EINVAL,
+               "conv2d: input (%lld B) or weights (%lld B) exceed the 2 GiB buffer-descriptor range", (long long)in_bytes,
+               (long long)wt_bytes);
+    k.in_bytes = (unsigned)in_bytes; k.wt_bytes = (unsigned)wt_bytes;
     k.in_cstride = d->in_cstride; k.in_coff = d->in_coff;
     k.out_cstride = d->out_cstride; k.out_coff = d->out_coff;
     k.res_cstride = d->res_cstride; k.res_coff = d->res_coff;
