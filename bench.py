@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristic instead of measuring")
     ap.add_argument("--per-op", action="store_true", help="also print the per-op time table to stderr")
     args = ap.parse_args()
 
@@ -88,6 +89,11 @@ def main():
     lo, hi = D.shard_range(args.batch * world, rank, world)    # this rank's slice of the global batch
     imgs = torch.from_numpy(W.synth_images(hi - lo, args.size, seed=0, first_index=lo)).to(eng.device)
     outs = eng.alloc_outputs(hi - lo)
+    if not args.no_autotune:
+        eng.predict_device(imgs, outs)                        # real activations in the workspace
+        tiles = eng.autotune(hi - lo)                         # untimed, one-off: fastest tile per layer (bit-identical results)
+    else:
+        tiles = None
 
     for _ in range(args.warmup):
         eng.predict_device(imgs, outs)
@@ -138,6 +144,7 @@ def main():
                                                                max(total_ms, 1e-9), 4)},
         }
         if args.per_op:
+            print("tiles:", tiles, file=sys.stderr)
             for name, ms in ops:
                 fl = plan.convs[int(name[1:])].flops_per_image * (hi - lo) if name.startswith("c") else 0
                 print(f"{name:8s} {ms:8.4f} ms  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.1f} TFLOP/s", file=sys.stderr)

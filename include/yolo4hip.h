@@ -125,6 +125,12 @@ int y4_predict(y4_handle h, const float* imgs_nhwc_dev, int n, float* boxes_dev,
 int y4_profile(y4_handle h, const float* imgs_nhwc_dev, int n, float* op_ms, char* names, int cap,
                int* n_ops, void* stream);
 
+/* Measured per-layer tile selection for batch n (call once after y4_pack_weights; optional).  Every tile
+ * configuration gives bit-identical outputs, so this affects speed only.  y4_get_tiles reports the choice
+ * per conv index (0 = built-in heuristic). */
+int y4_autotune(y4_handle h, int n, int reps, void* stream);
+int y4_get_tiles(y4_handle h, int32_t* tiles, int cap);
+
 /* Live per-op timing of the calls in between: while a session is open, each y4_predict (up to max_steps of
  * them) records a HIP event on its stream after every op, without synchronising.  y4_timing_end
  * synchronises the stream and returns the mean device time per op in ms ('c1'.., 'spp', 'decode', 'nms'). */

@@ -306,25 +306,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
 struct TileCfg {
     int bm, bn, wm, wn, bkb, nst;
 };
-// id 1..N; the table is also what tests sweep through y4_conv_desc.tile
-static const TileCfg kTiles[] = {
-    {128, 128, 2, 2, 128, 2},  // 1
-    {128, 128, 2, 2, 64, 2},   // 2
-    {128, 64, 4, 1, 128, 2},   // 3
-    {128, 64, 4, 1, 64, 2},    // 4
-    {128, 32, 4, 1, 128, 2},   // 5
-    {128, 32, 4, 1, 64, 2},    // 6
-    {256, 128, 4, 2, 128, 2},  // 7
-    {256, 128, 4, 2, 64, 2},   // 8
-    {64, 128, 1, 4, 128, 2},   // 9
-    {128, 128, 2, 2, 128, 3},  // 10
-    {128, 128, 2, 2, 128, 4},  // 11
-    {128, 128, 2, 2, 64, 4},   // 12
-    {256, 128, 4, 2, 128, 3},  // 13
-    {64, 128, 1, 4, 128, 4},   // 14
-    {128, 64, 4, 1, 128, 4},   // 15
-    {128, 64, 4, 1, 64, 4},    // 16
-};
+// id, BM (pixels), BN (channels), WM, WN (wave grid), BKB (bytes of K per LDS row), NST (ring stages).
+// The table is also what tests and the autotuner sweep through y4_conv_desc.tile.
+#define Y4_TILES(X)            \
+    X(1, 128, 128, 2, 2, 128, 2)  \
+    X(2, 128, 128, 2, 2, 64, 2)   \
+    X(3, 128, 64, 4, 1, 128, 2)   \
+    X(4, 128, 64, 4, 1, 64, 2)    \
+    X(5, 128, 32, 4, 1, 128, 2)   \
+    X(6, 128, 32, 4, 1, 64, 2)    \
+    X(7, 256, 128, 4, 2, 128, 2)  \
+    X(8, 64, 128, 1, 4, 128, 2)   \
+    X(9, 64, 128, 1, 4, 64, 2)    \
+    X(10, 64, 64, 2, 2, 128, 2)   \
+    X(11, 64, 64, 2, 2, 64, 2)    \
+    X(12, 64, 256, 1, 4, 128, 2)  \
+    X(13, 128, 256, 2, 4, 128, 2) \
+    X(14, 128, 128, 2, 2, 128, 3) \
+    X(15, 128, 64, 4, 1, 64, 4)   \
+    X(16, 32, 128, 1, 4, 128, 2)  \
+    X(17, 64, 128, 1, 4, 128, 3)
+
+#define Y4_TILE_ROW(id, bm, bn, wm, wn, bkb, nst) {bm, bn, wm, wn, bkb, nst},
+static const TileCfg kTiles[] = {Y4_TILES(Y4_TILE_ROW)};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 int conv_tile_count() { return kNumTiles; }
@@ -345,24 +349,9 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
 
 template <int DT>
 static int launch_dt(int tile, const ConvK& k, hipStream_t s) {
-    switch (tile) {
-        case 1: return launch_cfg<DT, 128, 128, 2, 2, 128, 2>(k, s);
-        case 2: return launch_cfg<DT, 128, 128, 2, 2, 64, 2>(k, s);
-        case 3: return launch_cfg<DT, 128, 64, 4, 1, 128, 2>(k, s);
-        case 4: return launch_cfg<DT, 128, 64, 4, 1, 64, 2>(k, s);
-        case 5: return launch_cfg<DT, 128, 32, 4, 1, 128, 2>(k, s);
-        case 6: return launch_cfg<DT, 128, 32, 4, 1, 64, 2>(k, s);
-        case 7: return launch_cfg<DT, 256, 128, 4, 2, 128, 2>(k, s);
-        case 8: return launch_cfg<DT, 256, 128, 4, 2, 64, 2>(k, s);
-        case 9: return launch_cfg<DT, 64, 128, 1, 4, 128, 2>(k, s);
-        case 10: return launch_cfg<DT, 128, 128, 2, 2, 128, 3>(k, s);
-        case 11: return launch_cfg<DT, 128, 128, 2, 2, 128, 4>(k, s);
-        case 12: return launch_cfg<DT, 128, 128, 2, 2, 64, 4>(k, s);
-        case 13: return launch_cfg<DT, 256, 128, 4, 2, 128, 3>(k, s);
-        case 14: return launch_cfg<DT, 64, 128, 1, 4, 128, 4>(k, s);
-        case 15: return launch_cfg<DT, 128, 64, 4, 1, 128, 4>(k, s);
-        case 16: return launch_cfg<DT, 128, 64, 4, 1, 64, 4>(k, s);
-    }
+#define Y4_TILE_CASE(id, bm, bn, wm, wn, bkb, nst) \
+    case id: return launch_cfg<DT, bm, bn, wm, wn, bkb, nst>(k, s);
+    switch (tile) { Y4_TILES(Y4_TILE_CASE) }
     set_error("conv2d: unknown tile id %d", tile);
     return Y4_EINVAL;
 }
@@ -379,7 +368,7 @@ int conv_pick_tile(int dtype, int M, int cin, int cout) {
     const bool k128 = cin % (128 / es) == 0;
     if (cout <= 32) return k128 ? 5 : 6;
     if (cout <= 64) return k128 ? 3 : 4;
-    return k128 ? 1 : 2;
+    return k128 ? 8 : 9;      // 64x128: more, smaller blocks overlap load / MFMA / store phases best (measured)
 }
 
 int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream) {
@@ -428,6 +417,7 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
                d->cin, cout_pad);
     k.grid_m = (k.M + tc.bm - 1) / tc.bm;
     k.grid_n = (int)((round_up(d->cout, 8) + tc.bn - 1) / tc.bn);
+    Y4_REQUIRE((int64_t)k.grid_n * tc.bn <= cout_pad, Y4_EINVAL, "conv2d: tile %d overruns the packed weight rows", tile);
     switch (d->dtype) {
         case Y4_F32: return launch_dt<Y4_F32>(tile, k, stream);
         case Y4_BF16: return launch_dt<Y4_BF16>(tile, k, stream);

@@ -40,6 +40,7 @@ struct Op {
     int conv = -1;
     View in, out, res;
     bool has_res = false, upsample = false, out_f32 = false;
+    int tile = 0;          // 0 = heuristic; set by y4_autotune
     char name[16];
 };
 struct Layer {
@@ -268,7 +269,7 @@ int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s) {
     d.in = buf_ptr(h, op.in); d.wt = h->wts + L.w_off; d.scale = scale; d.shift = shift;
     d.out = buf_ptr(h, op.out);
     if (op.has_res) { d.res = buf_ptr(h, op.res); d.res_cstride = op.res.cstride; d.res_coff = op.res.coff; }
-    d.tile = 0;
+    d.tile = op.tile;
     return conv2d_launch(&d, h->act + h->zero_off, s);
 }
 
@@ -505,6 +506,50 @@ int y4_predict(y4_handle h, const float* imgs, int n, float* boxes, float* score
     const int rc = predict_impl(h, imgs, n, boxes, scores, classes, valid, kept_idx, (hipStream_t)stream, ev);
     if (ev && rc == Y4_OK) ++h->t_steps;
     return rc;
+}
+
+// Per-layer tile choice by measurement: every tile configuration that fits a conv is timed on the layer's
+// real shape (HIP events on `stream`, whatever data is in the workspace) and the fastest is kept.  All tiles
+// produce bit-identical results (same K order), so this changes speed only.
+int y4_autotune(y4_handle h, int n, int reps, void* stream) {
+    if (int r = check_ready(h, n)) return r;
+    Y4_REQUIRE(reps >= 1 && reps <= 100, Y4_EINVAL, "y4_autotune: reps %d", reps);
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    Y4_CHECK_HIP(hipEventCreate(&e0));
+    Y4_CHECK_HIP(hipEventCreate(&e1));
+    int rc = Y4_OK;
+    const int ntiles = conv_tile_count();
+    for (Op& op : h->ops) {
+        if (op.kind != OP_CONV) continue;
+        float best = 1e30f;
+        int best_tile = 0;
+        for (int tile = 1; tile <= ntiles && rc == Y4_OK; ++tile) {
+            op.tile = tile;
+            if (run_op(h, op, nullptr, n, s) != Y4_OK) continue;      // tile does not fit this shape
+            if (hipEventRecord(e0, s) != hipSuccess) { rc = Y4_EHIP; break; }
+            for (int i = 0; i < reps; ++i) run_op(h, op, nullptr, n, s);
+            float ms = 0.f;
+            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = Y4_EHIP; break; }
+            if (ms < best) { best = ms; best_tile = tile; }
+        }
+        op.tile = best_tile;
+        if (rc != Y4_OK) break;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != Y4_OK) set_error("y4_autotune: HIP event failure");
+    return rc;
+}
+
+int y4_get_tiles(y4_handle h, int32_t* tiles, int cap) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(tiles && cap >= (int)h->layers.size(), Y4_EINVAL, "y4_get_tiles: need room for %d layers", (int)h->layers.size());
+    for (int i = 0; i < (int)h->layers.size(); ++i) tiles[i] = 0;
+    for (const Op& op : h->ops)
+        if (op.kind == OP_CONV) tiles[op.conv] = op.tile;
+    return Y4_OK;
 }
 
 int y4_timing_begin(y4_handle h, int max_steps) {

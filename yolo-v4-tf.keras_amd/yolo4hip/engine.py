@@ -208,6 +208,15 @@ class Engine:
             ext.check(self.lib.y4_get_conv_output(self.handle, conv_idx, n, ext.ptr(out), out.numel(), ext.stream_ptr()))
         return out.cpu().numpy()
 
+    def autotune(self, n=None, reps=3):
+        """Pick the fastest tile configuration per conv layer by measurement (results are bit-identical)."""
+        n = int(n or self.max_batch)
+        with self.torch.cuda.device(self.device):
+            ext.check(self.lib.y4_autotune(self.handle, n, int(reps), ext.stream_ptr()))
+        tiles = (C.c_int32 * 110)()
+        ext.check(self.lib.y4_get_tiles(self.handle, tiles, 110))
+        return list(tiles)
+
     def timing_begin(self, max_steps):
         ext.check(self.lib.y4_timing_begin(self.handle, int(max_steps)))
 

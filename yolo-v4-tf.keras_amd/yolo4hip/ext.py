@@ -68,6 +68,8 @@ SYMBOLS = {
     "y4_decode_nms": (_I, [_VP, _I, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP]),
     "y4_predict": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "y4_profile": (_I, [_VP, _VP, _I, _VP, _VP, _I, C.POINTER(_I), _VP]),
+    "y4_autotune": (_I, [_VP, _I, _I, _VP]),
+    "y4_get_tiles": (_I, [_VP, C.POINTER(C.c_int32), _I]),
     "y4_timing_begin": (_I, [_VP, _I]),
     "y4_timing_end": (_I, [_VP, _VP, _VP, _I, C.POINTER(_I), C.POINTER(_I), _VP]),
     "y4_packed_conv_bytes": (_I, [_I, _I, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
