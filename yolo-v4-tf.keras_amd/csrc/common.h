@@ -34,30 +34,64 @@ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 constexpr int COUT_PAD = 128;      // packed weight matrices have a multiple of this many rows
 constexpr int ZERO_PAGE_BYTES = 256;
 
-// ---- device-side storage conversions (bf16 is raw uint16_t, fp16 is _Float16)
+// ---- device-side storage conversions (bf16 is stored as raw uint16_t, fp16 as _Float16).
+// Conversions go through the compiler's native __bf16 / _Float16 vector types so that gfx950's packed
+// converts (v_cvt_pk_bf16_f32: two round-to-nearest-even results per instruction) are used.
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
 __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                              // round to nearest even
-    return (uint16_t)(u >> 16);
-}
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 
 template <int DT> struct Elem;
 template <> struct Elem<Y4_F32> {
     using type = float;
+    static constexpr int EPC = 4;                               // elements per 16-byte chunk
     static __device__ __forceinline__ float ld(float v) { return v; }
     static __device__ __forceinline__ float st(float v) { return v; }
+    static __device__ __forceinline__ void load_chunk(const void* p, float* v) {
+        const f32x4_t x = *(const f32x4_t*)p;
+        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+    }
+    static __device__ __forceinline__ void store_chunk(void* p, const float* v) {
+        *(f32x4_t*)p = f32x4_t{v[0], v[1], v[2], v[3]};
+    }
 };
 template <> struct Elem<Y4_BF16> {
     using type = uint16_t;
+    static constexpr int EPC = 8;
     static __device__ __forceinline__ float ld(uint16_t v) { return bf16_to_f32(v); }
     static __device__ __forceinline__ uint16_t st(float v) { return f32_to_bf16(v); }
+    static __device__ __forceinline__ void load_chunk(const void* p, float* v) {
+        const u32x4_t x = *(const u32x4_t*)p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(x[i] << 16);
+            v[2 * i + 1] = __uint_as_float(x[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store_chunk(void* p, const float* v) {
+        const f32x8_t x = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+        *(bf16x8_t*)p = __builtin_convertvector(x, bf16x8_t);
+    }
 };
 template <> struct Elem<Y4_F16> {
     using type = _Float16;
+    static constexpr int EPC = 8;
     static __device__ __forceinline__ float ld(_Float16 v) { return (float)v; }
     static __device__ __forceinline__ _Float16 st(float v) { return (_Float16)v; }
+    static __device__ __forceinline__ void load_chunk(const void* p, float* v) {
+        const f32x8_t x = __builtin_convertvector(*(const f16x8_t*)p, f32x8_t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = x[i];
+    }
+    static __device__ __forceinline__ void store_chunk(void* p, const float* v) {
+        const f32x8_t x = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+        *(f16x8_t*)p = __builtin_convertvector(x, f16x8_t);
+    }
 };
 
 // Activations of the reference's conv() unit (custom_layers.py:5-31).
@@ -66,17 +100,53 @@ template <> struct Elem<Y4_F16> {
 // beyond its threshold).
 template <bool FAST>
 __device__ __forceinline__ float mish_f(float x) {
-    float e = FAST ? __expf(fminf(x, 20.f)) : expf(fminf(x, 20.f));
-    float n = e * (e + 2.f);
-    float t = FAST ? __fdividef(n, n + 2.f) : n / (n + 2.f);
-    return x > 20.f ? x : x * t;
+    if (FAST) {   // 16-bit storage paths: v_exp_f32 + v_rcp_f32 (~1 ulp each), far below bf16/fp16 resolution
+        const float e = __builtin_amdgcn_exp2f(fminf(x, 20.f) * 1.4426950408889634f);
+        const float n = e * (e + 2.f);
+        return x * (n * __builtin_amdgcn_rcpf(n + 2.f));          // x > 20: n/(n+2) rounds to 1 anyway
+    }
+    const float e = expf(fminf(x, 20.f));
+    const float n = e * (e + 2.f);
+    return x > 20.f ? x : x * (n / (n + 2.f));
+}
+
+// Exact unsigned division by a runtime-constant divisor for dividends < 2^31 (pixel indices): q = n / d via
+// one multiply-high and a shift; mul/shr are computed on the host (fastdiv_make).
+struct FastDiv {
+    uint32_t mul, shr, d;
+};
+inline FastDiv fastdiv_make(uint32_t d) {
+    FastDiv f{0, 0, d};
+    if (d <= 1) return f;
+    uint32_t lg = 0;
+    while ((1ull << lg) < d) ++lg;
+    const uint32_t p = 31 + lg;
+    f.mul = (uint32_t)(((1ull << p) + d - 1) / d);
+    f.shr = p - 32;
+    return f;
+}
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv f) {
+    return f.d <= 1 ? n : (__umulhi(n, f.mul) >> f.shr);
 }
 __device__ __forceinline__ float leaky_f(float x) { return x > 0.f ? x : 0.1f * x; }
+// max(x, 0.1x) == LeakyReLU(0.1) for every finite x; one v_max without the NaN-canonicalising v_max pair
+// that fmaxf() costs (16-bit paths only; the fp32 path keeps the select form above)
+__device__ __forceinline__ float leaky_fast(float x) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(0.1f * x));
+    return r;
+}
 
 template <bool FAST>
 __device__ __forceinline__ float apply_act(float x, int act) {
     if (act == Y4_ACT_MISH) return mish_f<FAST>(x);
-    if (act == Y4_ACT_LEAKY) return leaky_f(x);
+    if (act == Y4_ACT_LEAKY) return FAST ? leaky_fast(x) : leaky_f(x);
+    return x;
+}
+template <bool FAST, int ACT>
+__device__ __forceinline__ float apply_act_t(float x) {
+    if (ACT == Y4_ACT_MISH) return mish_f<FAST>(x);
+    if (ACT == Y4_ACT_LEAKY) return FAST ? leaky_fast(x) : leaky_f(x);
     return x;
 }
 

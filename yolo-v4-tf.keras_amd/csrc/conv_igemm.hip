@@ -16,6 +16,8 @@
 // ds_read_b128 lane group hits 16 distinct slots; global_load_lds writes LDS lane-linearly, so the
 // swizzle is applied to the per-lane SOURCE address and again on the fragment read (same involution).
 // Pipeline: 2 LDS stages, one barrier per K-tile: loads of tile t+1 fly during the MFMAs of tile t.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace y4 {
@@ -38,6 +40,8 @@ struct ConvK {
     int ksize, stride, pad, act, upsample, out_f32;
     int grid_m, grid_n;
     unsigned in_bytes, wt_bytes;   // buffer-descriptor extents (bounds-checked loads)
+    FastDiv div_howo, div_wo;      // m -> (n, ho, wo) without integer division
+    FastDiv div_gridn;
 };
 
 template <int CPR> __device__ __forceinline__ int swz(int row) {
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
         const int b = blockIdx.x, qq = nwg >> 3, rr = nwg & 7, xcd = b & 7, idx = b >> 3;
         t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
     }
-    const int tile_m = t / p.grid_n, tile_n = t - tile_m * p.grid_n;
+    const int tile_m = (int)fastdiv((uint32_t)t, p.div_gridn), tile_n = t - tile_m * p.grid_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,8 +139,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
         const int row = r0 + j * RPI;
         const int m = m0 + row;
         const int mm = m < p.M ? m : 0;
-        const int n = mm / HoWo, rem = mm - n * HoWo;
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int n = (int)fastdiv((uint32_t)mm, p.div_howo), rem = mm - n * HoWo;
+        const int ho = (int)fastdiv((uint32_t)rem, p.div_wo), wo = rem - ho * p.Wo;
         const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
         a_off[j] = (((n * p.H + hi0) * p.W + wi0) * p.in_cstride + p.in_coff + ((q ^ swz<CPR>(row)) * EPC)) * ES;
         a_hi[j] = m < p.M ? hi0 : -100000;     // rows past M never validate -> zeros
@@ -232,7 +236,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
         }
     }
 
-    // ---- epilogue: y = act(acc*scale + shift) (+ residual) -> NHWC slice store (optionally 2x2 replicated)
+    // ---- epilogue: y = act(acc*scale + shift) (+ residual) -> NHWC slice store (optionally 2x2 replicated).
+    // The activation is a compile-time tag inside (one uniform switch outside the pixel loop); conversions
+    // use the packed hardware converts (Elem<DT>::store_chunk).
     const int chb = n0 + wn * WCH + fg * CPL;       // this lane's first channel
     float sc[CPL], sh[CPL];
 #pragma unroll
@@ -243,63 +249,67 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
         for (int e = 0; e < 4; ++e) { sc[c + e] = s4[e]; sh[c + e] = h4[e]; }
     }
     constexpr bool FAST = (DT != Y4_F32);
+    auto epilogue = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-    for (int i = 0; i < MREP; ++i) {
-        const int m = m0 + wm * WPX + i * 16 + frow;
-        if (m >= p.M) continue;
-        float v[CPL];
+        for (int i = 0; i < MREP; ++i) {
+            const int m = m0 + wm * WPX + i * 16 + frow;
+            if (m >= p.M) continue;
+            float v[CPL];
 #pragma unroll
-        for (int j = 0; j < NREP; ++j)
+            for (int j = 0; j < NREP; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = j * 4 + r;
-                v[c] = apply_act<FAST>(acc[i][j][r] * sc[c] + sh[c], p.act);
-            }
-        if (p.res) {
-            const T* rp = (const T*)p.res + (int64_t)m * p.res_cstride + p.res_coff + chb;
-#pragma unroll
-            for (int c = 0; c < CPL; c += EPC) {
-                if (chb + c < p.cout_store) {
-                    const u32x4 raw = *(const u32x4*)(rp + c);
-                    const T* rv = (const T*)&raw;
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[c + e] += E::ld(rv[e]);
+                for (int r = 0; r < 4; ++r) {
+                    const int c = j * 4 + r;
+                    v[c] = apply_act_t<FAST, ACT>(fmaf(acc[i][j][r], sc[c], sh[c]));
                 }
-            }
-        }
-        int64_t pix[4];
-        int npix = 1;
-        if (p.upsample) {
-            const int n = m / HoWo, rem = m - n * HoWo;
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            const int W2 = 2 * p.Wo;
-            const int64_t base = ((int64_t)n * 2 * p.Ho + 2 * ho) * W2 + 2 * wo;
-            pix[0] = base; pix[1] = base + 1; pix[2] = base + W2; pix[3] = base + W2 + 1;
-            npix = 4;
-        } else {
-            pix[0] = m;
-        }
-        for (int u = 0; u < npix; ++u) {
-            if (p.out_f32) {
-                float* op = (float*)p.out + pix[u] * p.out_cstride + p.out_coff + chb;
-#pragma unroll
-                for (int c = 0; c < CPL; c += 4)
-                    if (chb + c < p.cout_store) *(f32x4*)(op + c) = f32x4{v[c], v[c + 1], v[c + 2], v[c + 3]};
-            } else {
-                T* op = (T*)p.out + pix[u] * p.out_cstride + p.out_coff + chb;
+            if (p.res) {
+                const T* rp = (const T*)p.res + (int64_t)m * p.res_cstride + p.res_coff + chb;
 #pragma unroll
                 for (int c = 0; c < CPL; c += EPC) {
                     if (chb + c < p.cout_store) {
-                        u32x4 raw;
-                        T* ov = (T*)&raw;
+                        float rv[EPC];
+                        E::load_chunk(rp + c, rv);
 #pragma unroll
-                        for (int e = 0; e < EPC; ++e) ov[e] = E::st(v[c + e]);
-                        *(u32x4*)(op + c) = raw;
+                        for (int e = 0; e < EPC; ++e) v[c + e] += rv[e];
                     }
                 }
             }
+            int64_t pix[4];
+            int npix = 1;
+            if (p.upsample) {
+                const int n = (int)fastdiv((uint32_t)m, p.div_howo), rem = m - n * HoWo;
+                const int ho = (int)fastdiv((uint32_t)rem, p.div_wo), wo = rem - ho * p.Wo;
+                const int W2 = 2 * p.Wo;
+                const int64_t base = ((int64_t)n * 2 * p.Ho + 2 * ho) * W2 + 2 * wo;
+                pix[0] = base; pix[1] = base + 1; pix[2] = base + W2; pix[3] = base + W2 + 1;
+                npix = 4;
+            } else {
+                pix[0] = m;
+            }
+            if (p.out_f32) {
+                for (int u = 0; u < npix; ++u) {
+                    float* op = (float*)p.out + pix[u] * p.out_cstride + p.out_coff + chb;
+#pragma unroll
+                    for (int c = 0; c < CPL; c += 4)
+                        if (chb + c < p.cout_store) Elem<Y4_F32>::store_chunk(op + c, v + c);
+                }
+            } else {
+                u32x4 packed[CPL / EPC];
+#pragma unroll
+                for (int c = 0; c < CPL; c += EPC) E::store_chunk(&packed[c / EPC], v + c);
+                for (int u = 0; u < npix; ++u) {
+                    T* op = (T*)p.out + pix[u] * p.out_cstride + p.out_coff + chb;
+#pragma unroll
+                    for (int c = 0; c < CPL; c += EPC)
+                        if (chb + c < p.cout_store) *(u32x4*)(op + c) = packed[c / EPC];
+                }
+            }
         }
-    }
+    };
+    if (p.act == Y4_ACT_MISH) epilogue(std::integral_constant<int, Y4_ACT_MISH>{});
+    else if (p.act == Y4_ACT_LEAKY) epilogue(std::integral_constant<int, Y4_ACT_LEAKY>{});
+    else epilogue(std::integral_constant<int, Y4_ACT_LINEAR>{});
 }
 
 // ------------------------------------------------------------------------------------------- launch
@@ -403,6 +413,7 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
                "conv2d: input (%lld B) or weights (%lld B) exceed the 2 GiB buffer-descriptor range", (long long)in_bytes,
                (long long)wt_bytes);
     k.in_bytes = (unsigned)in_bytes; k.wt_bytes = (unsigned)wt_bytes;
+    k.div_howo = fastdiv_make((uint32_t)(k.Ho * k.Wo)); k.div_wo = fastdiv_make((uint32_t)k.Wo);
     k.in_cstride = d->in_cstride; k.in_coff = d->in_coff;
     k.out_cstride = d->out_cstride; k.out_coff = d->out_coff;
     k.res_cstride = d->res_cstride; k.res_coff = d->res_coff;
@@ -418,6 +429,7 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
     k.grid_m = (k.M + tc.bm - 1) / tc.bm;
     k.grid_n = (int)((round_up(d->cout, 8) + tc.bn - 1) / tc.bn);
     Y4_REQUIRE((int64_t)k.grid_n * tc.bn <= cout_pad, Y4_EINVAL, "conv2d: tile %d overruns the packed weight rows", tile);
+    k.div_gridn = fastdiv_make((uint32_t)k.grid_n);
     switch (d->dtype) {
         case Y4_F32: return launch_dt<Y4_F32>(tile, k, stream);
         case Y4_BF16: return launch_dt<Y4_BF16>(tile, k, stream);
