@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyolo4hip.so")
+# YOLO4HIP_LIB lets kernel experiments (scripts/, scratch builds) load an alternative build of the SAME ABI
+LIB_PATH = os.environ.get("YOLO4HIP_LIB") or os.path.join(_HERE, "libyolo4hip.so")
 
 F32, BF16, F16 = 0, 1, 2
 DTYPE_IDS = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "f16": F16, "fp16": F16,
