@@ -249,12 +249,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
         for (int e = 0; e < 4; ++e) { sc[c + e] = s4[e]; sh[c + e] = h4[e]; }
     }
     constexpr bool FAST = (DT != Y4_F32);
-    auto epilogue = [&](auto act_tag) {
+    // FULL (block-uniform): every pixel row of the tile is < M and every channel chunk is stored -> no per-row /
+    // per-chunk predicates at all; partial tiles (last M tile, the heads' last channel tile) take the masked path.
+    auto epilogue = [&](auto act_tag, auto full_tag) {
         constexpr int ACT = decltype(act_tag)::value;
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int mrow = m0 + wm * WPX + frow;
+        const T* const res_base = (const T*)p.res + (int64_t)mrow * p.res_cstride + p.res_coff + chb;
 #pragma unroll
         for (int i = 0; i < MREP; ++i) {
-            const int m = m0 + wm * WPX + i * 16 + frow;
-            if (m >= p.M) continue;
+            const int m = mrow + i * 16;
+            if (!FULL && m >= p.M) continue;
             float v[CPL];
 #pragma unroll
             for (int j = 0; j < NREP; ++j)
@@ -264,10 +269,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
                     v[c] = apply_act_t<FAST, ACT>(fmaf(acc[i][j][r], sc[c], sh[c]));
                 }
             if (p.res) {
-                const T* rp = (const T*)p.res + (int64_t)m * p.res_cstride + p.res_coff + chb;
+                const T* rp = res_base + (int64_t)(i * 16) * p.res_cstride;
 #pragma unroll
                 for (int c = 0; c < CPL; c += EPC) {
-                    if (chb + c < p.cout_store) {
+                    if (FULL || chb + c < p.cout_store) {
                         float rv[EPC];
                         E::load_chunk(rp + c, rv);
 #pragma unroll
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
                     float* op = (float*)p.out + pix[u] * p.out_cstride + p.out_coff + chb;
 #pragma unroll
                     for (int c = 0; c < CPL; c += 4)
-                        if (chb + c < p.cout_store) Elem<Y4_F32>::store_chunk(op + c, v + c);
+                        if (FULL || chb + c < p.cout_store) Elem<Y4_F32>::store_chunk(op + c, v + c);
                 }
             } else {
                 u32x4 packed[CPL / EPC];
@@ -302,14 +307,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
                     T* op = (T*)p.out + pix[u] * p.out_cstride + p.out_coff + chb;
 #pragma unroll
                     for (int c = 0; c < CPL; c += EPC)
-                        if (chb + c < p.cout_store) *(u32x4*)(op + c) = packed[c / EPC];
+                        if (FULL || chb + c < p.cout_store) *(u32x4*)(op + c) = packed[c / EPC];
                 }
             }
         }
     };
-    if (p.act == Y4_ACT_MISH) epilogue(std::integral_constant<int, Y4_ACT_MISH>{});
-    else if (p.act == Y4_ACT_LEAKY) epilogue(std::integral_constant<int, Y4_ACT_LEAKY>{});
-    else epilogue(std::integral_constant<int, Y4_ACT_LINEAR>{});
+    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.cout_store);
+    using TT = std::true_type;
+    using FF = std::false_type;
+    if (p.act == Y4_ACT_MISH) {
+        if (full) epilogue(std::integral_constant<int, Y4_ACT_MISH>{}, TT{});
+        else epilogue(std::integral_constant<int, Y4_ACT_MISH>{}, FF{});
+    } else if (p.act == Y4_ACT_LEAKY) {
+        if (full) epilogue(std::integral_constant<int, Y4_ACT_LEAKY>{}, TT{});
+        else epilogue(std::integral_constant<int, Y4_ACT_LEAKY>{}, FF{});
+    } else {
+        if (full) epilogue(std::integral_constant<int, Y4_ACT_LINEAR>{}, TT{});
+        else epilogue(std::integral_constant<int, Y4_ACT_LINEAR>{}, FF{});
+    }
 }
 
 // ------------------------------------------------------------------------------------------- launch
@@ -335,7 +350,8 @@ struct TileCfg {
     X(14, 128, 128, 2, 2, 128, 3) \
     X(15, 128, 64, 4, 1, 64, 4)   \
     X(16, 32, 128, 1, 4, 128, 2)  \
-    X(17, 64, 128, 1, 4, 128, 3)
+    X(17, 64, 128, 1, 4, 128, 3)  \
+    X(18, 256, 256, 2, 4, 128, 2)
 
 #define Y4_TILE_ROW(id, bm, bn, wm, wn, bkb, nst) {bm, bn, wm, wn, bkb, nst},
 static const TileCfg kTiles[] = {Y4_TILES(Y4_TILE_ROW)};
