@@ -2,11 +2,11 @@
 //   yolov4_head/get_boxes (custom_layers.py:201-258)  -> decode_kernel
 //   nms() = tf.image.combined_non_max_suppression (custom_layers.py:261-298) -> nms_kernel
 //
-// decode_kernel: one wavefront per grid cell.  The cell's 3*(5+C) raw logits are one contiguous run of the
-// NHWC head, read coalesced into LDS; lanes then sweep the (anchor, class) pairs, form
-// score = sigmoid(obj)*sigmoid(cls) and append the ones with score > score_threshold (strict) to the
-// image's candidate list with ONE wave-aggregated atomic (ballot + mbcnt).  Lanes 0..2 decode the three
-// boxes.  A candidate is a 64-bit key  (score bits << 32) | ~(box_index*C + class): sorting keys
+// decode_kernel: one lane per box reads its objectness logit; boxes whose sigmoid(obj) alone is not above the
+// score threshold cannot yield candidates and are dropped at once; the wave then sweeps the class logits of
+// the surviving boxes (coalesced), forms score = sigmoid(obj)*sigmoid(cls) and appends the ones with
+// score > score_threshold (strict) to the image's candidate list with ONE wave-aggregated atomic per pass
+// (ballot + popcount).  Only surviving boxes are decoded to coordinates.  A candidate is a 64-bit key  (score bits << 32) | ~(box_index*C + class): sorting keys
 // descending gives (score desc, box index asc, class asc) -- the tie order this build defines.
 //
 // nms_kernel: one workgroup per image.  Class-aware greedy NMS is done in ONE pass over the globally
@@ -27,66 +27,80 @@ namespace y4 {
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// One lane per (cell, anchor) box.  Because score = sigmoid(obj)*sigmoid(cls) <= sigmoid(obj) in float32
+// (sigmoid <= 1), a box whose objectness alone is not > score_threshold cannot produce a candidate: each lane
+// reads just its objectness logit first (4 bytes) and the wave then sweeps, cooperatively and coalesced, the
+// class logits of the few boxes that pass (ballot loop).  Only those boxes are decoded to coordinates.
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeK p) {
-    extern __shared__ __attribute__((aligned(16))) float dsm[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t cell = (int64_t)blockIdx.x * 4 + wave;
-    if (cell >= (int64_t)p.N * p.cells_per_img) return;
-    const int n = (int)(cell / p.cells_per_img);
-    int rem = (int)(cell - (int64_t)n * p.cells_per_img);
-    int s = 0;
-    if (rem >= p.g[0] * p.g[0]) { rem -= p.g[0] * p.g[0]; s = 1; if (rem >= p.g[1] * p.g[1]) { rem -= p.g[1] * p.g[1]; s = 2; } }
-    const int g = p.g[s];
-    const int row = rem / g, col = rem - row * g;
-    const int nf = 5 + p.C, nval = 3 * nf;
-    float* v = dsm + wave * p.hcs;
-    const float* src = p.head[s] + ((int64_t)(n * g + row) * g + col) * p.hcs;
-    for (int e = lane; e < nval; e += 64) v[e] = src[e];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0);     // LDS writes of this wave are done (single-wave region, no s_barrier)
-    __builtin_amdgcn_wave_barrier();
-
-    const int box0 = p.box_off[s] + (row * g + col) * 3;
-    if (lane < 3) {
-        // custom_layers.py:251-256
-        const float* t = v + lane * nf;
-        const float bx = ((sigmoid_f(t[0]) * p.xyscale[s]) - p.xyoff[s] + (float)col) * (float)p.stride[s];
-        const float by = ((sigmoid_f(t[1]) * p.xyscale[s]) - p.xyoff[s] + (float)row) * (float)p.stride[s];
-        const float bw = expf(t[2]) * p.anchors[(s * 3 + lane) * 2 + 0];
-        const float bh = expf(t[3]) * p.anchors[(s * 3 + lane) * 2 + 1];
-        float4 o;
-        o.x = (bx - bw / 2.0f) / p.img_size;
-        o.y = (by - bh / 2.0f) / p.img_size;
-        o.z = (bx + bw / 2.0f) / p.img_size;
-        o.w = (by + bh / 2.0f) / p.img_size;
-        *(float4*)(p.dboxes + ((int64_t)n * p.nbox + box0 + lane) * 4) = o;
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;          // box id over all images
+    const int n = (int)(t / p.nbox);
+    const int b = (int)(t - (int64_t)n * p.nbox);                        // box index within the image
+    const bool in_range = n < p.N;
+    const int nf = 5 + p.C;
+    int s = 0, a = 0, cell = 0;
+    const float* cellp = nullptr;
+    float s_obj = 0.f;
+    if (in_range) {
+        const int c3 = b / 3;
+        a = b - c3 * 3;
+        const int n0 = p.g[0] * p.g[0], n1 = n0 + p.g[1] * p.g[1];
+        s = c3 >= n1 ? 2 : (c3 >= n0 ? 1 : 0);
+        cell = c3 - (s == 2 ? n1 : (s == 1 ? n0 : 0));
+        const int g = p.g[s];
+        cellp = p.head[s] + ((int64_t)n * g * g + cell) * p.hcs + a * nf;
+        s_obj = sigmoid_f(cellp[4]);
     }
-    const float obj0 = sigmoid_f(v[4]), obj1 = sigmoid_f(v[nf + 4]), obj2 = sigmoid_f(v[2 * nf + 4]);
-    unsigned long long* keys = p.keys + (int64_t)n * p.cap;
-    for (int e0 = 0; e0 < nval; e0 += 64) {
-        const int e = e0 + lane;
-        bool hit = false;
-        unsigned long long key = 0;
-        if (e < nval) {
-            const int a = e / nf, f = e - a * nf;
-            if (f >= 5) {
-                const float sc = (a == 0 ? obj0 : (a == 1 ? obj1 : obj2)) * sigmoid_f(v[e]);
+    unsigned long long todo = __ballot(in_range && s_obj > p.score_thr);
+    while (todo) {
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        // broadcast lane j's box
+        const float* bp = (const float*)__shfl((unsigned long long)(uintptr_t)cellp, j);
+        const float so = __shfl(s_obj, j);
+        const int bn = __shfl(n, j), bb = __shfl(b, j);
+        unsigned long long* keys = p.keys + (int64_t)bn * p.cap;
+        for (int c0 = 0; c0 < p.C; c0 += 64) {
+            const int c = c0 + lane;
+            bool hit = false;
+            unsigned long long key = 0;
+            if (c < p.C) {
+                // cheap screen first (v_exp_f32 + v_rcp_f32, ~1e-6 relative): the exact float32 sigmoid (IEEE
+                // expf + division, what the decision is defined on) runs only for scores within 0.2 % of the cut
+                const float x = bp[5 + c];
+                const float approx = so * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+                const float sc = approx > 0.998f * p.score_thr ? so * sigmoid_f(x) : 0.f;
                 if (sc > p.score_thr) {
                     hit = true;
-                    const uint32_t id = (uint32_t)(box0 + a) * (uint32_t)p.C + (uint32_t)(f - 5);
+                    const uint32_t id = (uint32_t)bb * (uint32_t)p.C + (uint32_t)c;
                     key = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(~id);
                 }
             }
-        }
-        const unsigned long long mask = __ballot(hit);
-        if (mask) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(p.counts + n, (uint32_t)__popcll(mask));
-            base = __shfl(base, 0);
-            if (hit) {
-                const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                if (pos < p.cap) keys[pos] = key;
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(p.counts + bn, (uint32_t)__popcll(mask));
+                base = __shfl(base, 0);
+                if (hit) {
+                    const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                    if (pos < p.cap) keys[pos] = key;
+                }
             }
+        }
+        if (lane == j) {
+            // custom_layers.py:251-256 (only boxes that can be candidates are ever read back by the NMS stage)
+            const int g = p.g[s];
+            const int row = cell / g, col = cell - row * g;
+            const float bx = ((sigmoid_f(cellp[0]) * p.xyscale[s]) - p.xyoff[s] + (float)col) * (float)p.stride[s];
+            const float by = ((sigmoid_f(cellp[1]) * p.xyscale[s]) - p.xyoff[s] + (float)row) * (float)p.stride[s];
+            const float bw = expf(cellp[2]) * p.anchors[(s * 3 + a) * 2 + 0];
+            const float bh = expf(cellp[3]) * p.anchors[(s * 3 + a) * 2 + 1];
+            float4 o;
+            o.x = (bx - bw / 2.0f) / p.img_size;
+            o.y = (by - bh / 2.0f) / p.img_size;
+            o.z = (bx + bw / 2.0f) / p.img_size;
+            o.w = (by + bh / 2.0f) / p.img_size;
+            *(float4*)(p.dboxes + ((int64_t)n * p.nbox + b) * 4) = o;
         }
     }
 }
@@ -272,10 +286,8 @@ size_t nms_lds_bytes(int max_total) { return (size_t)SORT_CAP * 24 + (size_t)max
 
 int decode_launch(const DecodeK& k, hipStream_t stream) {
     Y4_CHECK_HIP(hipMemsetAsync(k.counts, 0, sizeof(uint32_t) * k.N, stream));
-    const int64_t cells = (int64_t)k.N * k.cells_per_img;
-    const int blocks = (int)((cells + 3) / 4);
-    const size_t lds = (size_t)4 * k.hcs * sizeof(float);
-    hipLaunchKernelGGL(decode_kernel, dim3(blocks), dim3(256), lds, stream, k);
+    const int64_t boxes = (int64_t)k.N * k.nbox;
+    hipLaunchKernelGGL(decode_kernel, dim3((int)((boxes + 255) / 256)), dim3(256), 0, stream, k);
     Y4_CHECK_HIP(hipGetLastError());
     return Y4_OK;
 }

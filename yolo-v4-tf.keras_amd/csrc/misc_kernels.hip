@@ -154,20 +154,117 @@ __global__ __launch_bounds__(256) void spp_kernel(typename Elem<DT>::type* __res
     *(u32x4*)(op + 2 * C) = o5;
 }
 
+// LDS-resident separable version (used when the 19x19 / 13x13 plane fits): one workgroup per (image, group of
+// 4 channel chunks = 64 bytes per pixel).  The plane is staged in LDS once; pass 1 forms the horizontal running
+// maxima of radius 2/4/6 (13 LDS reads -> 3 results, nested windows), pass 2 the vertical ones (5+9+13 reads) and
+// writes the three concat slices: 40 LDS reads per output chunk instead of 169 global loads.
+template <int DT>
+__global__ __launch_bounds__(256) void spp_lds_kernel(typename Elem<DT>::type* __restrict__ buf, int N, int S, int C) {
+    using E = Elem<DT>;
+    using T = typename E::type;
+    constexpr int EPC = E::EPC;
+    extern __shared__ __attribute__((aligned(16))) char ssm[];
+    const int P = S * S;
+    u32x4* X = (u32x4*)ssm;             // [P][4]
+    u32x4* H2 = X + P * 4;
+    u32x4* H4 = H2 + P * 4;
+    u32x4* H6 = H4 + P * 4;
+    const int groups = C / (4 * EPC);
+    const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
+    const int cs = 4 * C;
+    T* const img = buf + (int64_t)n * P * cs;
+    const int ch0 = g * 4 * EPC;
+    for (int t = threadIdx.x; t < P * 4; t += 256) {
+        const int px = t >> 2, q = t & 3;
+        X[t] = *(const u32x4*)(img + (int64_t)px * cs + 3 * C + ch0 + q * EPC);
+    }
+    __syncthreads();
+    auto upd = [](float* m, const u32x4& raw) {
+        float v[EPC];
+        E::load_chunk(&raw, v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) m[e] = fmaxf(m[e], v[e]);
+    };
+    auto pack = [](const float* m) {
+        u32x4 o;
+        E::store_chunk(&o, m);
+        return o;
+    };
+    for (int t = threadIdx.x; t < P * 4; t += 256) {
+        const int px = t >> 2, q = t & 3;
+        const int y = px / S, x = px - y * S;
+        float m[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) m[e] = -INFINITY;
+        const u32x4* row = X + (y * S) * 4 + q;
+        for (int dx = -2; dx <= 2; ++dx)
+            if ((unsigned)(x + dx) < (unsigned)S) upd(m, row[(x + dx) * 4]);
+        H2[t] = pack(m);
+        for (int k = 3; k <= 4; ++k) {
+            if (x - k >= 0) upd(m, row[(x - k) * 4]);
+            if (x + k < S) upd(m, row[(x + k) * 4]);
+        }
+        H4[t] = pack(m);
+        for (int k = 5; k <= 6; ++k) {
+            if (x - k >= 0) upd(m, row[(x - k) * 4]);
+            if (x + k < S) upd(m, row[(x + k) * 4]);
+        }
+        H6[t] = pack(m);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < P * 4; t += 256) {
+        const int px = t >> 2, q = t & 3;
+        const int y = px / S, x = px - y * S;
+        float m5[EPC], m9[EPC], m13[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) m5[e] = m9[e] = m13[e] = -INFINITY;
+        for (int dy = -6; dy <= 6; ++dy) {
+            const int yy = y + dy;
+            if ((unsigned)yy >= (unsigned)S) continue;
+            const int o = (yy * S + x) * 4 + q;
+            const int ady = dy < 0 ? -dy : dy;
+            upd(m13, H6[o]);
+            if (ady <= 4) upd(m9, H4[o]);
+            if (ady <= 2) upd(m5, H2[o]);
+        }
+        T* op = img + (int64_t)px * cs + ch0 + q * EPC;
+        *(u32x4*)(op) = pack(m13);
+        *(u32x4*)(op + C) = pack(m9);
+        *(u32x4*)(op + 2 * C) = pack(m5);
+    }
+}
+
+template <int DT>
+static int spp_dispatch(void* buf, int n, int side, int c, hipStream_t stream) {
+    using T = typename Elem<DT>::type;
+    constexpr int EPC = Elem<DT>::EPC;
+    const size_t lds = (size_t)side * side * 4 * 16 * 4;
+    if (c % (4 * EPC) == 0 && lds <= 150 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            Y4_CHECK_HIP(hipFuncSetAttribute((const void*)spp_lds_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(spp_lds_kernel<DT>, dim3(n * (c / (4 * EPC))), dim3(256), lds, stream, (T*)buf, n, side, c);
+    } else {
+        const int64_t total = (int64_t)n * side * side * (c / EPC);
+        hipLaunchKernelGGL(spp_kernel<DT>, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, (T*)buf, n, side, c);
+    }
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
 int spp_launch(int dtype, void* buf, int n, int side, int c, hipStream_t stream) {
     Y4_REQUIRE(buf && n > 0 && side > 0, Y4_EINVAL, "spp: bad arguments");
     const int epc = 16 / elem_size(dtype);
     Y4_REQUIRE(c % epc == 0, Y4_EINVAL, "spp: channels %d not a multiple of %d", c, epc);
-    const int64_t total = (int64_t)n * side * side * (c / epc);
-    const int blocks = (int)((total + 255) / 256);
     switch (dtype) {
-        case Y4_F32: hipLaunchKernelGGL(spp_kernel<Y4_F32>, dim3(blocks), dim3(256), 0, stream, (float*)buf, n, side, c); break;
-        case Y4_BF16: hipLaunchKernelGGL(spp_kernel<Y4_BF16>, dim3(blocks), dim3(256), 0, stream, (uint16_t*)buf, n, side, c); break;
-        case Y4_F16: hipLaunchKernelGGL(spp_kernel<Y4_F16>, dim3(blocks), dim3(256), 0, stream, (_Float16*)buf, n, side, c); break;
-        default: set_error("spp: bad dtype %d", dtype); return Y4_EINVAL;
+        case Y4_F32: return spp_dispatch<Y4_F32>(buf, n, side, c, stream);
+        case Y4_BF16: return spp_dispatch<Y4_BF16>(buf, n, side, c, stream);
+        case Y4_F16: return spp_dispatch<Y4_F16>(buf, n, side, c, stream);
     }
-    Y4_CHECK_HIP(hipGetLastError());
-    return Y4_OK;
+    set_error("spp: bad dtype %d", dtype);
+    return Y4_EINVAL;
 }
 
 // ----------------------------------------------------------------------- view -> dense float32 copy
