@@ -146,15 +146,15 @@ def main():
         if args.per_op:
             print("tiles:", tiles, file=sys.stderr)
             for name, ms in ops:
-                fl = plan.convs[int(name[1:])].flops_per_image * (hi - lo) if name.startswith("c") else 0
+                fl = sum(plan.convs[int(i)].flops_per_image for i in name[1:].split("+")) * (hi - lo) if name.startswith("c") else 0
                 print(f"{name:8s} {ms:8.4f} ms  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.1f} TFLOP/s", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             ws = ws_holder.get("ws") or W.synth_weights(plan, seed=0)
             line["cpu_baseline"] = cpu_baseline(args.size, args.classes, ws, cfg)
         print(json.dumps(line), flush=True)
     D.barrier()
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -157,6 +157,10 @@ typedef struct y4_conv_desc {
     const void* res;
     void* out;
     int32_t tile;                  /* 0 = auto; otherwise a tile-config id (see y4_conv_tile_count) */
+    /* optional second output view: channels [split, cout) are stored to out2 (channel c -> out2_coff + c - split).
+     * Used to run a CSP block's route conv and main-in conv (same input, custom_layers.py:58-60) as ONE GEMM. */
+    void* out2;
+    int32_t out2_cstride, out2_coff, split;
 } y4_conv_desc;
 
 /* cout_pad (rows of the packed matrix) and bytes needed for a packed kernel */

@@ -42,6 +42,8 @@ struct ConvK {
     unsigned in_bytes, wt_bytes;   // buffer-descriptor extents (bounds-checked loads)
     FastDiv div_howo, div_wo;      // m -> (n, ho, wo) without integer division
     FastDiv div_gridn;
+    char* out2;                    // channels >= split go to this view (fused CSP route + main-in pair)
+    int out2_cstride, out2_coff, split;
 };
 
 template <int CPR> __device__ __forceinline__ int swz(int row) {
@@ -255,6 +257,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
         constexpr int ACT = decltype(act_tag)::value;
         constexpr bool FULL = decltype(full_tag)::value;
         const int mrow = m0 + wm * WPX + frow;
+        // split output: a lane's CPL channels never straddle `split` (both are multiples of CPL)
+        const bool second = p.split > 0 && chb >= p.split;
+        char* const out_ptr = second ? p.out2 : p.out;
+        const int out_cs = second ? p.out2_cstride : p.out_cstride;
+        const int out_co = (second ? p.out2_coff - p.split : p.out_coff) + chb;
         const T* const res_base = (const T*)p.res + (int64_t)mrow * p.res_cstride + p.res_coff + chb;
 #pragma unroll
         for (int i = 0; i < MREP; ++i) {
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
             }
             if (p.out_f32) {
                 for (int u = 0; u < npix; ++u) {
-                    float* op = (float*)p.out + pix[u] * p.out_cstride + p.out_coff + chb;
+                    float* op = (float*)out_ptr + pix[u] * out_cs + out_co;
 #pragma unroll
                     for (int c = 0; c < CPL; c += 4)
                         if (FULL || chb + c < p.cout_store) Elem<Y4_F32>::store_chunk(op + c, v + c);
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
 #pragma unroll
                 for (int c = 0; c < CPL; c += EPC) E::store_chunk(&packed[c / EPC], v + c);
                 for (int u = 0; u < npix; ++u) {
-                    T* op = (T*)p.out + pix[u] * p.out_cstride + p.out_coff + chb;
+                    T* op = (T*)out_ptr + pix[u] * out_cs + out_co;
 #pragma unroll
                     for (int c = 0; c < CPL; c += EPC)
                         if (FULL || chb + c < p.cout_store) *(u32x4*)(op + c) = packed[c / EPC];
@@ -446,6 +453,10 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
     k.grid_n = (int)((round_up(d->cout, 8) + tc.bn - 1) / tc.bn);
     Y4_REQUIRE((int64_t)k.grid_n * tc.bn <= cout_pad, Y4_EINVAL, "conv2d: tile %d overruns the packed weight rows", tile);
     k.div_gridn = fastdiv_make((uint32_t)k.grid_n);
+    k.out2 = (char*)d->out2; k.out2_cstride = d->out2_cstride; k.out2_coff = d->out2_coff; k.split = d->out2 ? d->split : 0;
+    Y4_REQUIRE(!d->out2 || (d->split > 0 && d->split % 32 == 0 && d->split < d->cout && !d->res && !d->upsample && !d->out_f32 &&
+                            d->out2_cstride % epc == 0 && d->out2_coff % epc == 0),
+               Y4_EINVAL, "conv2d: bad split-output description");
     switch (d->dtype) {
         case Y4_F32: return launch_dt<Y4_F32>(tile, k, stream);
         case Y4_BF16: return launch_dt<Y4_BF16>(tile, k, stream);

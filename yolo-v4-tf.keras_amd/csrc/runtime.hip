@@ -41,11 +41,17 @@ struct Op {
     View in, out, res;
     bool has_res = false, upsample = false, out_f32 = false;
     int tile = 0;          // 0 = heuristic; set by y4_autotune
+    int conv2 = -1;        // fused CSP pair: second conv index (main-in), its output view and the channel split
+    View out2;
+    int split = 0;
     char name[16];
 };
 struct Layer {
     y4_layer_desc d;
     int cout_pad;
+    int fused_with = -1;   // >= 0: this layer's rows live in layer `fused_with`'s packed matrix at row `fused_row`
+    int fused_row = 0;
+    int extra_rows = 0;    // rows appended by a fused partner
     size_t w_off, scale_off, shift_off;   // byte offsets in the wts workspace
 };
 
@@ -122,8 +128,20 @@ struct Builder {
     // csp_block (reference custom_layers.py:47-69): returns the [x, route] concat buffer
     View csp(View din, int width, int repeat, bool bottleneck) {
         View cat = alloc(din.side, 2 * width);
-        conv(din, slice(cat, width, width), width, 1, false, Y4_ACT_MISH);          // route (created first)
+        // route conv (created first) and main-in conv read the same tensor: ONE GEMM with 2*width output
+        // channels, [0,width) -> the route slice of the concat buffer, [width,2*width) -> x
+        conv(din, slice(cat, width, width), width, 1, false, Y4_ACT_MISH);          // route
         View x = conv_new(din, width, 1, false, Y4_ACT_MISH);                        // main-in
+        {
+            Op second = c.ops.back(); c.ops.pop_back();
+            Op& first = c.ops.back();
+            first.conv2 = second.conv; first.out2 = second.out; first.split = width;
+            snprintf(first.name, sizeof(first.name), "c%d+%d", first.conv, second.conv);
+            Layer& L1 = c.layers[first.conv];
+            Layer& L2 = c.layers[second.conv];
+            L2.fused_with = first.conv; L2.fused_row = width;
+            L1.extra_rows = width + COUT_PAD;      // partner rows + slack for its zero padding
+        }
         for (int r = 0; r < repeat; ++r) {                                           // residual_block :34-44
             View t = conv_new(x, bottleneck ? width / 2 : width, 1, false, Y4_ACT_MISH);
             View x2 = alloc(din.side, width);
@@ -228,11 +246,11 @@ void layout(y4_ctx& c) {
     // ---- weights
     off = 0;
     for (auto& L : c.layers) {
-        const size_t wbytes = L.d.idx == 0 ? (size_t)L.d.cout * 27 * 4
-                                           : (size_t)L.cout_pad * L.d.ksize * L.d.ksize * L.d.cin * c.es;
+        const size_t rows = (size_t)L.cout_pad + L.extra_rows;
+        const size_t wbytes = L.d.idx == 0 ? (size_t)L.d.cout * 27 * 4 : rows * L.d.ksize * L.d.ksize * L.d.cin * c.es;
         L.w_off = off; off = align256(off + wbytes);
-        L.scale_off = off; off = align256(off + (size_t)L.cout_pad * 4);
-        L.shift_off = off; off = align256(off + (size_t)L.cout_pad * 4);
+        L.scale_off = off; off = align256(off + rows * 4);
+        L.shift_off = off; off = align256(off + rows * 4);
     }
     c.wts_bytes = off;
 }
@@ -262,13 +280,14 @@ int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s) {
     y4_conv_desc d{};
     d.dtype = h->cfg.dtype;
     d.n = n; d.h = op.in.side; d.w = op.in.side; d.cin = op.in.c;
-    d.cout = L.d.cout; d.ksize = L.d.ksize; d.stride = L.d.stride; d.act = L.d.act;
+    d.cout = op.conv2 >= 0 ? 2 * L.d.cout : L.d.cout; d.ksize = L.d.ksize; d.stride = L.d.stride; d.act = L.d.act;
     d.upsample = op.upsample ? 1 : 0; d.out_f32 = op.out_f32 ? 1 : 0;
     d.in_cstride = op.in.cstride; d.in_coff = op.in.coff;
     d.out_cstride = op.out.cstride; d.out_coff = op.out.coff;
     d.in = buf_ptr(h, op.in); d.wt = h->wts + L.w_off; d.scale = scale; d.shift = shift;
     d.out = buf_ptr(h, op.out);
     if (op.has_res) { d.res = buf_ptr(h, op.res); d.res_cstride = op.res.cstride; d.res_coff = op.res.coff; }
+    if (op.conv2 >= 0) { d.out2 = buf_ptr(h, op.out2); d.out2_cstride = op.out2.cstride; d.out2_coff = op.out2.coff; d.split = op.split; }
     d.tile = op.tile;
     return conv2d_launch(&d, h->act + h->zero_off, s);
 }
@@ -400,13 +419,17 @@ int y4_pack_weights(y4_handle h, const float* blob, size_t n_floats, void* strea
     for (const Layer& L : h->layers) {
         const float* rec = blob + L.d.weight_offset;
         const float* w = rec + (L.d.has_bn ? 4 : 1) * (int64_t)L.d.cout;
-        if (int r = fold_bn_launch(rec, (float*)(h->wts + L.scale_off), (float*)(h->wts + L.shift_off), L.d.cout,
-                                   L.cout_pad, L.d.has_bn, s))
+        // a fused CSP pair shares one packed matrix: the partner's rows (and scale/shift) follow the first conv's
+        const Layer& D = L.fused_with >= 0 ? h->layers[L.fused_with] : L;
+        const size_t row_bytes = (size_t)L.d.ksize * L.d.ksize * L.d.cin * h->es;
+        char* wdst = h->wts + D.w_off + (size_t)L.fused_row * row_bytes;
+        if (int r = fold_bn_launch(rec, (float*)(h->wts + D.scale_off) + L.fused_row, (float*)(h->wts + D.shift_off) + L.fused_row,
+                                   L.d.cout, L.cout_pad, L.d.has_bn, s))
             return r;
         if (L.d.idx == 0) {
             if (int r = pack_stem_weights(w, (float*)(h->wts + L.w_off), L.d.cout, s)) return r;
         } else {
-            if (int r = pack_conv_weights(h->cfg.dtype, L.d.cout, L.d.cin, L.d.ksize, w, h->wts + L.w_off, s)) return r;
+            if (int r = pack_conv_weights(h->cfg.dtype, L.d.cout, L.d.cin, L.d.ksize, w, wdst, s)) return r;
         }
     }
     h->weights_ready = true;
@@ -457,8 +480,8 @@ int y4_set_heads(y4_handle h, int n, const float* in_s, const float* in_m, const
 int y4_get_conv_output(y4_handle h, int conv_idx, int n, float* out, size_t out_floats, void* stream) {
     if (int r = check_ready(h, n)) return r;
     for (const Op& op : h->ops) {
-        if (op.kind == OP_SPP || op.conv != conv_idx) continue;
-        const View& v = op.out;
+        if (op.kind == OP_SPP || (op.conv != conv_idx && op.conv2 != conv_idx)) continue;
+        const View& v = op.conv == conv_idx ? op.out : op.out2;
         const int64_t px = (int64_t)n * v.side * v.side;   // for an upsampling conv: the upsampled tensor
         Y4_REQUIRE((int64_t)out_floats >= px * v.c, Y4_EINVAL, "output buffer too small: %zu < %lld", out_floats,
                    (long long)(px * v.c));
@@ -548,7 +571,10 @@ int y4_get_tiles(y4_handle h, int32_t* tiles, int cap) {
     Y4_REQUIRE(tiles && cap >= (int)h->layers.size(), Y4_EINVAL, "y4_get_tiles: need room for %d layers", (int)h->layers.size());
     for (int i = 0; i < (int)h->layers.size(); ++i) tiles[i] = 0;
     for (const Op& op : h->ops)
-        if (op.kind == OP_CONV) tiles[op.conv] = op.tile;
+        if (op.kind == OP_CONV) {
+            tiles[op.conv] = op.tile;
+            if (op.conv2 >= 0) tiles[op.conv2] = op.tile;
+        }
     return Y4_OK;
 }
 

@@ -23,16 +23,19 @@ def init_process_group(backend=None):
     import torch
     import torch.distributed as dist
     rank, local_rank, world = env_world()
-    if world == 1:
-        return rank, local_rank, world
-    if not dist.is_initialized():
+    if world == 1 and "RANK" not in os.environ:
+        return rank, local_rank, world          # plain `python bench.py`: no process group at all
+    if not dist.is_initialized():               # under torchrun (even with one rank) the RCCL path is exercised
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
@@ -47,7 +50,7 @@ def shard_range(n_total, rank, world):
 def broadcast_bytes(buf, src=0):
     """Broadcast a uint8 tensor in place (the packed weight workspace)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.broadcast(buf, src=src)
     return buf
 
@@ -57,7 +60,7 @@ def load_weights_distributed(engine, make_flat, src=0):
     workspace is broadcast over RCCL; the other ranks adopt it without touching the file system."""
     import torch
     import torch.distributed as dist
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    multi = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if multi else 0
     if rank == src:
         engine.load_weight_blob(make_flat())
@@ -88,7 +91,7 @@ def gather_results(outs, n_total=None):
 def max_over_ranks(value):
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(value)
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
@@ -98,5 +101,5 @@ def max_over_ranks(value):
 
 def barrier():
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()

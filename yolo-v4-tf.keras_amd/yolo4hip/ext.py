@@ -44,7 +44,8 @@ class y4_conv_desc(C.Structure):
                 ("in_coff", C.c_int32), ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
                 ("res_cstride", C.c_int32), ("res_coff", C.c_int32), ("in_", C.c_void_p), ("wt", C.c_void_p),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("res", C.c_void_p), ("out", C.c_void_p),
-                ("tile", C.c_int32)]
+                ("tile", C.c_int32), ("out2", C.c_void_p), ("out2_cstride", C.c_int32), ("out2_coff", C.c_int32),
+                ("split", C.c_int32)]
 
 
 # every symbol include/yolo4hip.h declares: name -> (restype, argtypes)
