@@ -96,7 +96,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
     constexpr int CPR = BKB / 16;           // 16-byte chunks per LDS row
     constexpr int EPC = 16 / ES;            // elements per chunk
     constexpr int RPI = NT / CPR;           // rows staged per block-wide load instruction
-    constexpr int A_IT = BM / RPI;
+    constexpr int A_IT = (BM + RPI - 1) / RPI;          // last iteration is predicated when BM % RPI != 0
+    constexpr bool A_PART = BM % RPI != 0;
     constexpr int B_IT = BN >= RPI ? BN / RPI : 1;      // BN < RPI: only the first BN*CPR threads stage weights
     constexpr bool B_PART = BN < RPI;
     constexpr int WPX = BM / WM, WCH = BN / WN;
@@ -104,10 +105,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
     constexpr int CPL = 4 * NREP;           // consecutive channels a lane owns
     constexpr int STAGE = (BM + BN) * BKB;
     constexpr int KSTEPS = BKB / 64;        // MFMA k-steps (4 chunks each) per tile
-    static_assert(BM % RPI == 0 && (BN % RPI == 0 || (RPI % BN == 0 && (BN * CPR) % 64 == 0)), "tile rows vs rows-per-iteration");
+    static_assert(BM % 16 == 0 && (BN % RPI == 0 || (RPI % BN == 0 && (BN * CPR) % 64 == 0)), "tile rows vs rows-per-iteration");
     static_assert(MREP >= 1 && NREP >= 1, "wave tile");
     constexpr int LPT = A_IT + B_IT;        // LDS-DMA instructions a wave issues per stage
-    static_assert(NST >= 2 && NST <= 4 && (NST == 2 || !B_PART), "deep pipelines need uniform loads per wave");
+    static_assert(NST >= 2 && NST <= 4 && (NST == 2 || (!B_PART && !A_PART)), "deep pipelines need uniform loads per wave");
     static_assert((NST - 2) * LPT <= 63, "vmcnt field");
     using E = Elem<DT>;
     using T = typename E::type;
@@ -178,7 +179,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
         const int db = da + BM * BKB;
 #pragma unroll
         for (int j = 0; j < A_IT; ++j)
-            buffer_load16_lds(rs_in, smem + da + j * (NT * 16), a_vo[j], c0b);
+            if (!A_PART || r0 + j * RPI < BM)                                // wave-uniform (8 rows per wave, BM % 16 == 0)
+                buffer_load16_lds(rs_in, smem + da + j * (NT * 16), a_vo[j], c0b);
 #pragma unroll
         for (int j = 0; j < B_IT; ++j)
             if (!B_PART || tid < BN * CPR)                                   // wave-uniform predicate
@@ -358,7 +360,18 @@ struct TileCfg {
     X(15, 128, 64, 4, 1, 64, 4)   \
     X(16, 32, 128, 1, 4, 128, 2)  \
     X(17, 64, 128, 1, 4, 128, 3)  \
-    X(18, 256, 256, 2, 4, 128, 2)
+    X(18, 256, 256, 2, 4, 128, 2) \
+    X(19, 192, 256, 2, 4, 128, 2) \
+    X(20, 96, 128, 2, 2, 128, 2)  \
+    X(21, 96, 256, 2, 4, 128, 2)  \
+    X(22, 160, 256, 2, 4, 128, 2) \
+    X(23, 224, 256, 2, 4, 128, 2) \
+    X(24, 160, 128, 2, 2, 128, 2) \
+    X(25, 192, 128, 2, 2, 128, 2) \
+    X(26, 144, 128, 1, 4, 128, 2) \
+    X(27, 80, 128, 1, 4, 128, 2)  \
+    X(28, 48, 128, 1, 4, 128, 2)  \
+    X(29, 112, 128, 1, 4, 128, 2)
 
 #define Y4_TILE_ROW(id, bm, bn, wm, wn, bkb, nst) {bm, bn, wm, wn, bkb, nst},
 static const TileCfg kTiles[] = {Y4_TILES(Y4_TILE_ROW)};
@@ -380,12 +393,17 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
     return Y4_OK;
 }
 
+constexpr int F32_TILES = 12;
+
 template <int DT>
 static int launch_dt(int tile, const ConvK& k, hipStream_t s) {
-#define Y4_TILE_CASE(id, bm, bn, wm, wn, bkb, nst) \
-    case id: return launch_cfg<DT, bm, bn, wm, wn, bkb, nst>(k, s);
+    // the fp32 (parity) path instantiates only the first F32_TILES configurations (build time)
+#define Y4_TILE_CASE(id, bm, bn, wm, wn, bkb, nst)                                            \
+    case id:                                                                                  \
+        if constexpr (DT == Y4_F32 && (id > F32_TILES)) break;                                \
+        else return launch_cfg<DT, bm, bn, wm, wn, bkb, nst>(k, s);
     switch (tile) { Y4_TILES(Y4_TILE_CASE) }
-    set_error("conv2d: unknown tile id %d", tile);
+    set_error("conv2d: tile id %d is not available for this dtype", tile);
     return Y4_EINVAL;
 }
 
