@@ -63,6 +63,10 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristic instead of measuring")
+    ap.add_argument("--save-tiles", default=None, help="write the autotuned per-layer tile ids to this JSON file")
+    ap.add_argument("--load-tiles", default=None, help="use tile ids from this JSON file instead of autotuning")
+    ap.add_argument("--subbatch", type=int, default=0, help="images per sub-batch for the early layers (0 = whole batch)")
+    ap.add_argument("--sub-last-conv", type=int, default=16)
     ap.add_argument("--per-op", action="store_true", help="also print the per-op time table to stderr")
     args = ap.parse_args()
 
@@ -89,11 +93,19 @@ def main():
     lo, hi = D.shard_range(args.batch * world, rank, world)    # this rank's slice of the global batch
     imgs = torch.from_numpy(W.synth_images(hi - lo, args.size, seed=0, first_index=lo)).to(eng.device)
     outs = eng.alloc_outputs(hi - lo)
-    if not args.no_autotune:
+    if args.subbatch > 0:
+        eng.set_subbatch(args.subbatch, args.sub_last_conv)
+    if args.load_tiles:
+        tiles = json.load(open(args.load_tiles))["tiles"]
+        eng.set_tiles(tiles)
+    elif not args.no_autotune:
         eng.predict_device(imgs, outs)                        # real activations in the workspace
         tiles = eng.autotune(hi - lo)                         # untimed, one-off: fastest tile per layer (bit-identical results)
     else:
         tiles = None
+    if args.save_tiles and rank == 0 and tiles:
+        json.dump({"size": args.size, "classes": args.classes, "batch": args.batch, "dtype": args.dtype, "tiles": tiles},
+                  open(args.save_tiles, "w"))
 
     for _ in range(args.warmup):
         eng.predict_device(imgs, outs)

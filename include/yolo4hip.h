@@ -130,6 +130,14 @@ int y4_profile(y4_handle h, const float* imgs_nhwc_dev, int n, float* op_ms, cha
  * per conv index (0 = built-in heuristic). */
 int y4_autotune(y4_handle h, int n, int reps, void* stream);
 int y4_get_tiles(y4_handle h, int32_t* tiles, int cap);
+/* Restore a tile choice saved from y4_get_tiles (one entry per conv index; an id that does not fit its layer makes
+ * the next forward fail with Y4_EINVAL rather than compute anything different). */
+int y4_set_tiles(y4_handle h, const int32_t* tiles, int count);
+
+/* Scheduling knob (results unchanged): run the ops up to and including conv `last_conv` over `images` images at a
+ * time instead of the whole batch, so that the large early activations of a sub-batch are still resident in the
+ * 256 MiB Infinity Cache when their consumer runs.  images <= 0 turns it off. */
+int y4_set_subbatch(y4_handle h, int images, int last_conv);
 
 /* Live per-op timing of the calls in between: while a session is open, each y4_predict (up to max_steps of
  * them) records a HIP event on its stream after every op, without synchronising.  y4_timing_end

@@ -80,7 +80,12 @@ struct y4_ctx {
     bool weights_ready = false;
     // timing session (y4_timing_begin/end): per-op HIP events recorded by y4_predict
     std::vector<hipEvent_t> t_events;
-    int t_max_steps = 0, t_steps = 0, t_per_step = 0;
+    int t_max_steps = 0, t_steps = 0, t_per_step = 0, t_n = 0;
+    std::vector<int> t_slot_op;       // op index measured by each event slot of a step
+    // sub-batching: ops [0, sub_last_op] run over `sub_images` images at a time (keeps the large early
+    // activations of one sub-batch resident in the 256 MiB Infinity Cache between producer and consumer)
+    int sub_images = 0, sub_last_op = -1;
+    bool t_recorded_this_call = false;
 };
 
 namespace {
@@ -267,16 +272,36 @@ int check_ready(y4_handle h, int n) {
     return Y4_OK;
 }
 
-char* buf_ptr(y4_handle h, const View& v) { return h->act + h->bufs[v.buf].offset; }
+char* buf_ptr(y4_handle h, const View& v, int img0 = 0) {
+    const Buffer& b = h->bufs[v.buf];
+    return h->act + b.offset + (size_t)img0 * b.side * b.side * b.channels * (b.f32 ? 4 : h->es);
+}
 
-int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s) {
-    if (op.kind == OP_SPP) return spp_launch(h->cfg.dtype, buf_ptr(h, op.in), n, op.in.side, op.in.cstride / 4, s);
+struct Launch {
+    int op, img0, cnt;
+};
+// execution schedule for a batch of n images (see y4_set_subbatch)
+void build_schedule(y4_handle h, int n, std::vector<Launch>& out) {
+    out.clear();
+    const int nops = (int)h->ops.size();
+    int first_full = 0;
+    if (h->sub_images > 0 && h->sub_last_op >= 0 && n > h->sub_images) {
+        for (int img0 = 0; img0 < n; img0 += h->sub_images)
+            for (int i = 0; i <= h->sub_last_op; ++i) out.push_back({i, img0, n - img0 < h->sub_images ? n - img0 : h->sub_images});
+        first_full = h->sub_last_op + 1;
+    }
+    for (int i = first_full; i < nops; ++i) out.push_back({i, 0, n});
+}
+
+int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s, int img0 = 0) {
+    if (op.kind == OP_SPP) return spp_launch(h->cfg.dtype, buf_ptr(h, op.in, img0), n, op.in.side, op.in.cstride / 4, s);
     const Layer& L = h->layers[op.conv];
     const float* scale = (const float*)(h->wts + L.scale_off);
     const float* shift = (const float*)(h->wts + L.shift_off);
     if (op.kind == OP_STEM)
-        return stem_conv_launch(h->cfg.dtype, imgs, n, h->S, h->S, (const float*)(h->wts + L.w_off), scale, shift,
-                                L.d.cout, L.d.act, buf_ptr(h, op.out), op.out.cstride, op.out.coff, s);
+        return stem_conv_launch(h->cfg.dtype, imgs ? imgs + (size_t)img0 * h->S * h->S * 3 : imgs, n, h->S, h->S,
+                                (const float*)(h->wts + L.w_off), scale, shift, L.d.cout, L.d.act,
+                                buf_ptr(h, op.out, img0), op.out.cstride, op.out.coff, s);
     y4_conv_desc d{};
     d.dtype = h->cfg.dtype;
     d.n = n; d.h = op.in.side; d.w = op.in.side; d.cin = op.in.c;
@@ -284,10 +309,10 @@ int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s) {
     d.upsample = op.upsample ? 1 : 0; d.out_f32 = op.out_f32 ? 1 : 0;
     d.in_cstride = op.in.cstride; d.in_coff = op.in.coff;
     d.out_cstride = op.out.cstride; d.out_coff = op.out.coff;
-    d.in = buf_ptr(h, op.in); d.wt = h->wts + L.w_off; d.scale = scale; d.shift = shift;
-    d.out = buf_ptr(h, op.out);
-    if (op.has_res) { d.res = buf_ptr(h, op.res); d.res_cstride = op.res.cstride; d.res_coff = op.res.coff; }
-    if (op.conv2 >= 0) { d.out2 = buf_ptr(h, op.out2); d.out2_cstride = op.out2.cstride; d.out2_coff = op.out2.coff; d.split = op.split; }
+    d.in = buf_ptr(h, op.in, img0); d.wt = h->wts + L.w_off; d.scale = scale; d.shift = shift;
+    d.out = buf_ptr(h, op.out, img0);
+    if (op.has_res) { d.res = buf_ptr(h, op.res, img0); d.res_cstride = op.res.cstride; d.res_coff = op.res.coff; }
+    if (op.conv2 >= 0) { d.out2 = buf_ptr(h, op.out2, img0); d.out2_cstride = op.out2.cstride; d.out2_coff = op.out2.coff; d.split = op.split; }
     d.tile = op.tile;
     return conv2d_launch(&d, h->act + h->zero_off, s);
 }
@@ -446,8 +471,10 @@ int y4_adopt_packed_weights(y4_handle h) {
 int y4_forward(y4_handle h, const float* imgs, int n, void* stream) {
     if (int r = check_ready(h, n)) return r;
     Y4_REQUIRE(imgs, Y4_EINVAL, "y4_forward: null images");
-    for (const Op& op : h->ops)
-        if (int r = run_op(h, op, imgs, n, (hipStream_t)stream)) return r;
+    std::vector<Launch> sched;
+    build_schedule(h, n, sched);
+    for (const Launch& l : sched)
+        if (int r = run_op(h, h->ops[l.op], imgs, l.cnt, (hipStream_t)stream, l.img0)) return r;
     return Y4_OK;
 }
 
@@ -506,10 +533,22 @@ static int predict_impl(y4_handle h, const float* imgs, int n, float* boxes, flo
                         int32_t* valid, int32_t* kept_idx, hipStream_t s, hipEvent_t* ev) {
     if (int r = check_ready(h, n)) return r;
     Y4_REQUIRE(imgs && boxes && scores && classes && valid, Y4_EINVAL, "y4_predict: null argument");
+    std::vector<Launch> sched;
+    build_schedule(h, n, sched);
+    if (ev && (int)sched.size() + 3 > h->t_per_step) ev = nullptr;       // cannot happen: sized for max_batch
+    if (ev && h->t_steps == 0) {
+        h->t_n = n;
+        h->t_slot_op.clear();
+        for (const Launch& l : sched) h->t_slot_op.push_back(l.op);
+        h->t_slot_op.push_back((int)h->ops.size());
+        h->t_slot_op.push_back((int)h->ops.size() + 1);
+    }
+    if (ev && n != h->t_n) ev = nullptr;                                   // a session times steps of one batch size
+    h->t_recorded_this_call = ev != nullptr;
     int i = 0;
     if (ev) Y4_CHECK_HIP(hipEventRecord(ev[0], s));
-    for (const Op& op : h->ops) {
-        if (int r = run_op(h, op, imgs, n, s)) return r;
+    for (const Launch& l : sched) {
+        if (int r = run_op(h, h->ops[l.op], imgs, l.cnt, s, l.img0)) return r;
         if (ev) Y4_CHECK_HIP(hipEventRecord(ev[++i], s));
     }
     for (int stage = 1; stage <= 2; ++stage) {
@@ -527,7 +566,7 @@ int y4_predict(y4_handle h, const float* imgs, int n, float* boxes, float* score
     hipEvent_t* ev = nullptr;
     if (h->t_max_steps > 0 && h->t_steps < h->t_max_steps) ev = h->t_events.data() + (size_t)h->t_steps * h->t_per_step;
     const int rc = predict_impl(h, imgs, n, boxes, scores, classes, valid, kept_idx, (hipStream_t)stream, ev);
-    if (ev && rc == Y4_OK) ++h->t_steps;
+    if (ev && rc == Y4_OK && h->t_recorded_this_call) ++h->t_steps;
     return rc;
 }
 
@@ -543,15 +582,17 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
     Y4_CHECK_HIP(hipEventCreate(&e1));
     int rc = Y4_OK;
     const int ntiles = conv_tile_count();
-    for (Op& op : h->ops) {
+    for (int oi = 0; oi < (int)h->ops.size(); ++oi) {
+        Op& op = h->ops[oi];
         if (op.kind != OP_CONV) continue;
+        const int ne = (h->sub_images > 0 && oi <= h->sub_last_op && n > h->sub_images) ? h->sub_images : n;
         float best = 1e30f;
         int best_tile = 0;
         for (int tile = 1; tile <= ntiles && rc == Y4_OK; ++tile) {
             op.tile = tile;
-            if (run_op(h, op, nullptr, n, s) != Y4_OK) continue;      // tile does not fit this shape
+            if (run_op(h, op, nullptr, ne, s) != Y4_OK) continue;     // tile does not fit this shape
             if (hipEventRecord(e0, s) != hipSuccess) { rc = Y4_EHIP; break; }
-            for (int i = 0; i < reps; ++i) run_op(h, op, nullptr, n, s);
+            for (int i = 0; i < reps; ++i) run_op(h, op, nullptr, ne, s);
             float ms = 0.f;
             if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
                 hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = Y4_EHIP; break; }
@@ -564,6 +605,30 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
     (void)hipEventDestroy(e1);
     if (rc != Y4_OK) set_error("y4_autotune: HIP event failure");
     return rc;
+}
+
+int y4_set_tiles(y4_handle h, const int32_t* tiles, int count) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(tiles && count == (int)h->layers.size(), Y4_EINVAL, "y4_set_tiles: expected %d entries", (int)h->layers.size());
+    for (Op& op : h->ops)
+        if (op.kind == OP_CONV) {
+            Y4_REQUIRE(tiles[op.conv] >= 0 && tiles[op.conv] <= conv_tile_count(), Y4_EINVAL, "y4_set_tiles: tile id %d", tiles[op.conv]);
+            op.tile = tiles[op.conv];
+        }
+    return Y4_OK;
+}
+
+int y4_set_subbatch(y4_handle h, int images, int last_conv) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(h->t_max_steps == 0, Y4_ESTATE, "y4_set_subbatch: a timing session is open");
+    if (images <= 0) { h->sub_images = 0; h->sub_last_op = -1; return Y4_OK; }
+    int last_op = -1;
+    for (int i = 0; i < (int)h->ops.size(); ++i)
+        if (h->ops[i].kind != OP_SPP && (h->ops[i].conv == last_conv || h->ops[i].conv2 == last_conv)) last_op = i;
+    Y4_REQUIRE(last_op >= 0, Y4_EINVAL, "y4_set_subbatch: no conv %d", last_conv);
+    h->sub_images = images;
+    h->sub_last_op = last_op;
+    return Y4_OK;
 }
 
 int y4_get_tiles(y4_handle h, int32_t* tiles, int cap) {
@@ -582,7 +647,11 @@ int y4_timing_begin(y4_handle h, int max_steps) {
     if (int r = check_handle(h)) return r;
     Y4_REQUIRE(max_steps >= 1 && max_steps <= 4096, Y4_EINVAL, "y4_timing_begin: max_steps %d", max_steps);
     Y4_REQUIRE(h->t_max_steps == 0, Y4_ESTATE, "a timing session is already open");
-    h->t_per_step = (int)h->ops.size() + 3;
+    {
+        std::vector<Launch> sched;
+        build_schedule(h, h->cfg.max_batch, sched);
+        h->t_per_step = (int)sched.size() + 3;
+    }
     h->t_events.resize((size_t)max_steps * h->t_per_step);
     for (auto& e : h->t_events) Y4_CHECK_HIP(hipEventCreate(&e));
     h->t_max_steps = max_steps;
@@ -604,15 +673,17 @@ int y4_timing_end(y4_handle h, float* op_ms_mean, char* names, int cap, int* n_o
         rc = Y4_EHIP;
     }
     if (rc == Y4_OK) {
-        for (int j = 0; j < nops; ++j) {
-            double acc = 0.0;
-            for (int st = 0; st < h->t_steps; ++st) {
+        std::vector<double> acc(nops, 0.0);
+        for (int st = 0; st < h->t_steps; ++st) {
+            hipEvent_t* ev = h->t_events.data() + (size_t)st * h->t_per_step;
+            for (int k = 0; k < (int)h->t_slot_op.size(); ++k) {
                 float ms = 0.f;
-                hipEvent_t* ev = h->t_events.data() + (size_t)st * h->t_per_step;
-                if (hipEventElapsedTime(&ms, ev[j], ev[j + 1]) != hipSuccess) { rc = Y4_EHIP; set_error("hipEventElapsedTime failed"); }
-                acc += ms;
+                if (hipEventElapsedTime(&ms, ev[k], ev[k + 1]) != hipSuccess) { rc = Y4_EHIP; set_error("hipEventElapsedTime failed"); }
+                acc[h->t_slot_op[k]] += ms;          // a sub-batched op has several slots per step
             }
-            op_ms_mean[j] = h->t_steps ? (float)(acc / h->t_steps) : 0.f;
+        }
+        for (int j = 0; j < nops; ++j) {
+            op_ms_mean[j] = h->t_steps ? (float)(acc[j] / h->t_steps) : 0.f;
             if (names) {
                 memset(names + 16 * j, 0, 16);
                 const char* nm = j < (int)h->ops.size() ? h->ops[j].name : (j == (int)h->ops.size() ? "decode" : "nms");

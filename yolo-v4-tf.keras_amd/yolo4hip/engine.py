@@ -217,6 +217,15 @@ class Engine:
         ext.check(self.lib.y4_get_tiles(self.handle, tiles, 110))
         return list(tiles)
 
+    def set_tiles(self, tiles):
+        arr = (C.c_int32 * len(tiles))(*[int(t) for t in tiles])
+        ext.check(self.lib.y4_set_tiles(self.handle, arr, len(tiles)))
+
+    def set_subbatch(self, images, last_conv=16):
+        """Run convs 0..last_conv over `images` images at a time (Infinity-Cache residency of the big early
+        activations); 0 turns it off.  Results are unchanged."""
+        ext.check(self.lib.y4_set_subbatch(self.handle, int(images), int(last_conv)))
+
     def timing_begin(self, max_steps):
         ext.check(self.lib.y4_timing_begin(self.handle, int(max_steps)))
 
