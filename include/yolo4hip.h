@@ -180,8 +180,9 @@ int y4_pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* o
  * optional UpSampling2D (custom_layers.py:147,159) + concat-slice store (custom_layers.py:68,...). */
 int y4_conv2d(const y4_conv_desc* d, void* stream);
 int y4_conv_tile_count(void);
-/* Stem conv (cin = 3, reference custom_layers.py:101): float32 images -> dtype.  Weights are the float32
- * table [(ky*3+kx)*3+ci][cout] made by y4_pack_stem_weights from Darknet (cout,3,3,3) order. */
+/* Stem conv (cin = 3, reference custom_layers.py:101): float32 images -> dtype.  `wk_dev` is an 8192-byte table
+ * made by y4_pack_stem_weights from Darknet (cout,3,3,3) order: float32 [(ky*3+kx)*3+ci][cout] for the fp32
+ * kernel, then (byte 4096 / 6144) the bf16 / fp16 MFMA weight fragments used by the 16-bit kernels. */
 int y4_pack_stem_weights(const float* w_oihw_dev, float* wk_dev, int cout, void* stream);
 int y4_stem_conv(int dtype, const float* imgs_dev, int n, int h, int w, const float* wk_dev,
                  const float* scale, const float* shift, int cout, int act, void* out_dev, int out_cstride,

@@ -63,18 +63,112 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     }
 }
 
-// Darknet (cout,3,3,3) -> [(ky*3+kx)*3+ci][cout] float table for the stem kernel
+// MFMA stem for the 16-bit paths.  GEMM view D[ch][px] = sum_k Wt[ch][k] * X[px][k] with K = 27 padded to 32:
+// ONE v_mfma_f32_16x16x32 per 16 pixels x 16 channels.  The pixel operand is gathered straight from the float32
+// image into registers (lane = (pixel l&15, k-chunk l>>4): 8 taps, converted to the 16-bit type), the weight
+// operand is a pre-built fragment table (channel rows permuted so that each lane ends up with 8 CONSECUTIVE
+// channels of its pixel -> one 16-byte store per lane, 1 KiB contiguous per wave).  No LDS.
+typedef __attribute__((ext_vector_type(4))) float stem_f32x4;
+typedef __attribute__((ext_vector_type(8))) short stem_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 stem_f16x8;
+
+template <int DT>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ img, const u32x4* __restrict__ wfrag,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        typename Elem<DT>::type* __restrict__ out, int N, int H, int W,
+                                                        int out_cstride, int out_coff, int act, FastDiv div_hw,
+                                                        FastDiv div_w, int tiles_per_wave) {
+    using E = Elem<DT>;
+    using T = typename E::type;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane & 15, g = lane >> 4;
+    const u32x4 wf0 = wfrag[lane], wf1 = wfrag[64 + lane];
+    // this lane's 8 taps k = 8g .. 8g+7  ->  (dy, dx, float offset), fixed for the whole kernel
+    int dyx[8], toff[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * g + e;
+        const int ky = k / 9, j = k - ky * 9, kx = j / 3, ci = j - kx * 3;
+        const bool real = k < 27;
+        dyx[e] = real ? (((ky - 1) & 0xffff) << 16) | ((kx - 1) & 0xffff) : 0x40004000;     // pad taps never validate
+        toff[e] = ((ky - 1) * W + (kx - 1)) * 3 + ci;
+    }
+    float sc[8], sh[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sc[c] = scale[g * 8 + c]; sh[c] = shift[g * 8 + c]; }
+    const int64_t total = (int64_t)N * H * W;
+    const int HW = H * W;
+    int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * tiles_per_wave * 16;
+    constexpr bool FAST = true;
+    for (int t = 0; t < tiles_per_wave; ++t, p0 += 16) {
+        if (p0 >= total) break;                                   // wave-uniform
+        const int64_t p = p0 + q;
+        const bool pv = p < total;
+        const uint32_t pp = (uint32_t)(pv ? p : total - 1);
+        const int n = (int)fastdiv(pp, div_hw);
+        const int rem = (int)pp - n * HW;
+        const int y = (int)fastdiv((uint32_t)rem, div_w), x = rem - y * W;
+        const float* base = img + (int64_t)pp * 3;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int dy = (short)(dyx[e] >> 16), dx = (short)(dyx[e] & 0xffff);
+            const bool ok = (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
+            v[e] = ok ? base[toff[e]] : 0.f;
+        }
+        u32x4 xf;
+        E::store_chunk(&xf, v);
+        stem_f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        if (DT == Y4_BF16) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(stem_bf16x8, wf0), __builtin_bit_cast(stem_bf16x8, xf), a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(stem_bf16x8, wf1), __builtin_bit_cast(stem_bf16x8, xf), a1, 0, 0, 0);
+        } else {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(stem_f16x8, wf0), __builtin_bit_cast(stem_f16x8, xf), a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(stem_f16x8, wf1), __builtin_bit_cast(stem_f16x8, xf), a1, 0, 0, 0);
+        }
+        float o[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o[r] = apply_act<FAST>(fmaf(a0[r], sc[r], sh[r]), act);
+            o[4 + r] = apply_act<FAST>(fmaf(a1[r], sc[4 + r], sh[4 + r]), act);
+        }
+        if (pv) {
+            u32x4 packed;
+            E::store_chunk(&packed, o);
+            *(u32x4*)(out + p * out_cstride + out_coff + g * 8) = packed;
+        }
+    }
+}
+
+// Darknet (cout,3,3,3) -> (a) [(ky*3+kx)*3+ci][cout] float table for the fp32 stem kernel at wk[0..27*cout),
+// (b) at byte 4096 the bf16 and at byte 6144 the fp16 MFMA weight-fragment tables [2 frags][64 lanes][8]:
+//     fragment jn, lane l holds row i = l&15 = g'*4 + r'  <->  channel g'*8 + jn*4 + r', taps k = 8*(l>>4) .. +7
 __global__ void pack_stem_kernel(const float* __restrict__ w_oihw, float* __restrict__ wk, int cout) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 27 * cout) return;
-    const int co = i % cout, k = i / cout;
-    const int ci = k % 3, tap = k / 3;
-    wk[i] = w_oihw[(co * 3 + ci) * 9 + tap];
+    if (i < 27 * cout) {
+        const int co = i % cout, k = i / cout;
+        const int ci = k % 3, tap = k / 3;
+        wk[i] = w_oihw[(co * 3 + ci) * 9 + tap];
+    }
+    if (cout == 32 && i < 2 * 64 * 8) {
+        const int e = i & 7, l = (i >> 3) & 63, jn = i >> 9;
+        const int row = l & 15, gq = row >> 2, rr = row & 3;
+        const int ch = gq * 8 + jn * 4 + rr;
+        const int k = 8 * (l >> 4) + e;
+        float v = 0.f;
+        if (k < 27) {
+            const int ci = k % 3, tap = k / 3;
+            v = w_oihw[(ch * 3 + ci) * 9 + tap];
+        }
+        ((uint16_t*)((char*)wk + 4096))[i] = Elem<Y4_BF16>::st(v);
+        ((_Float16*)((char*)wk + 6144))[i] = Elem<Y4_F16>::st(v);
+    }
 }
 
 int pack_stem_weights(const float* w_oihw, float* wk, int cout, hipStream_t stream) {
     Y4_REQUIRE(w_oihw && wk && cout > 0, Y4_EINVAL, "pack_stem_weights: bad argument");
-    hipLaunchKernelGGL(pack_stem_kernel, dim3((27 * cout + 255) / 256), dim3(256), 0, stream, w_oihw, wk, cout);
+    const int work = 27 * cout > 1024 ? 27 * cout : 1024;
+    hipLaunchKernelGGL(pack_stem_kernel, dim3((work + 255) / 256), dim3(256), 0, stream, w_oihw, wk, cout);
     Y4_CHECK_HIP(hipGetLastError());
     return Y4_OK;
 }
@@ -87,12 +181,21 @@ int stem_conv_launch(int dtype, const float* imgs, int n, int h, int w, const fl
     const int epc = 16 / elem_size(dtype);
     Y4_REQUIRE(out_cstride % epc == 0 && out_coff % epc == 0, Y4_EINVAL, "stem_conv: output view not 16-byte aligned");
     const int64_t total = (int64_t)n * h * w;
-    const int blocks = (int)((total + 255) / 256);
-    switch (dtype) {
-        case Y4_F32: hipLaunchKernelGGL((stem_conv_kernel<Y4_F32, 32>), dim3(blocks), dim3(256), 0, stream, imgs, wk, scale, shift, (float*)out, n, h, w, out_cstride, out_coff, act); break;
-        case Y4_BF16: hipLaunchKernelGGL((stem_conv_kernel<Y4_BF16, 32>), dim3(blocks), dim3(256), 0, stream, imgs, wk, scale, shift, (uint16_t*)out, n, h, w, out_cstride, out_coff, act); break;
-        case Y4_F16: hipLaunchKernelGGL((stem_conv_kernel<Y4_F16, 32>), dim3(blocks), dim3(256), 0, stream, imgs, wk, scale, shift, (_Float16*)out, n, h, w, out_cstride, out_coff, act); break;
-        default: set_error("stem_conv: bad dtype %d", dtype); return Y4_EINVAL;
+    Y4_REQUIRE(total * 3 < (1ll << 31), Y4_EINVAL, "stem_conv: image batch too large");
+    if (dtype == Y4_F32) {
+        hipLaunchKernelGGL((stem_conv_kernel<Y4_F32, 32>), dim3((int)((total + 255) / 256)), dim3(256), 0, stream, imgs, wk, scale, shift,
+                           (float*)out, n, h, w, out_cstride, out_coff, act);
+    } else {
+        const int tpw = 8;                                        // 16-pixel tiles per wave
+        const int blocks = (int)((total + 4 * tpw * 16 - 1) / (4 * tpw * 16));
+        const FastDiv dhw = fastdiv_make((uint32_t)(h * w)), dw = fastdiv_make((uint32_t)w);
+        if (dtype == Y4_BF16)
+            hipLaunchKernelGGL(stem_mfma_kernel<Y4_BF16>, dim3(blocks), dim3(256), 0, stream, imgs, (const u32x4*)((const char*)wk + 4096),
+                               scale, shift, (uint16_t*)out, n, h, w, out_cstride, out_coff, act, dhw, dw, tpw);
+        else if (dtype == Y4_F16)
+            hipLaunchKernelGGL(stem_mfma_kernel<Y4_F16>, dim3(blocks), dim3(256), 0, stream, imgs, (const u32x4*)((const char*)wk + 6144),
+                               scale, shift, (_Float16*)out, n, h, w, out_cstride, out_coff, act, dhw, dw, tpw);
+        else { set_error("stem_conv: bad dtype %d", dtype); return Y4_EINVAL; }
     }
     Y4_CHECK_HIP(hipGetLastError());
     return Y4_OK;

@@ -252,7 +252,7 @@ void layout(y4_ctx& c) {
     off = 0;
     for (auto& L : c.layers) {
         const size_t rows = (size_t)L.cout_pad + L.extra_rows;
-        const size_t wbytes = L.d.idx == 0 ? (size_t)L.d.cout * 27 * 4 : rows * L.d.ksize * L.d.ksize * L.d.cin * c.es;
+        const size_t wbytes = L.d.idx == 0 ? (size_t)8192 : rows * L.d.ksize * L.d.ksize * L.d.cin * c.es;
         L.w_off = off; off = align256(off + wbytes);
         L.scale_off = off; off = align256(off + rows * 4);
         L.shift_off = off; off = align256(off + rows * 4);
