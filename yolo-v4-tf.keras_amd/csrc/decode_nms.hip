@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeK p) {
             const unsigned long long mask = __ballot(hit);
             if (mask) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(p.counts + bn, (uint32_t)__popcll(mask));
+                if (lane == 0) base = atomicAdd(p.counts + (size_t)bn * COUNT_STRIDE, (uint32_t)__popcll(mask));
                 base = __shfl(base, 0);
                 if (hit) {
                     const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
@@ -102,6 +102,101 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeK p) {
             o.w = (by + bh / 2.0f) / p.img_size;
             *(float4*)(p.dboxes + ((int64_t)n * p.nbox + b) * 4) = o;
         }
+    }
+}
+
+// Variant for cells of at most 256 values (C <= 80): one wavefront per grid cell, the cell's 3*(5+C) logits are
+// read fully coalesced straight into registers (<= 4 per lane, one memory round trip), the three objectness
+// logits are broadcast by shuffles, and the 73 % of cells where no anchor can pass exit right there.
+__global__ __launch_bounds__(256) void decode_cell_kernel(const DecodeK p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t cellid = (int64_t)blockIdx.x * 4 + wave;
+    if (cellid >= (int64_t)p.N * p.cells_per_img) return;
+    const int n = (int)(cellid / p.cells_per_img);
+    int rem = (int)(cellid - (int64_t)n * p.cells_per_img);
+    int s = 0;
+    if (rem >= p.g[0] * p.g[0]) { rem -= p.g[0] * p.g[0]; s = 1; if (rem >= p.g[1] * p.g[1]) { rem -= p.g[1] * p.g[1]; s = 2; } }
+    const int g = p.g[s];
+    const int nf = 5 + p.C, nval = 3 * nf;
+    const float* src = p.head[s] + ((int64_t)n * g * g + rem) * p.hcs;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (lane + 64 * k < nval) ? src[lane + 64 * k] : 0.f;
+    auto value_at = [&](int e) {            // wave-uniform e: value e of the cell
+        const int k = e >> 6;
+        const float sel = k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3]));
+        return __shfl(sel, e & 63);
+    };
+    float so[3];
+    bool any = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        so[a] = sigmoid_f(value_at(a * nf + 4));
+        any = any || so[a] > p.score_thr;
+    }
+    if (!any) return;                       // wave-uniform
+    const int box0 = p.box_off[s] + rem * 3;
+    unsigned long long* keys = p.keys + (int64_t)n * p.cap;
+    const float cut = 0.998f * p.score_thr;
+    unsigned long long key[4];
+    unsigned long long mask[4];
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = lane + 64 * k;
+        bool hit = false;
+        key[k] = 0;
+        if (e < nval) {
+            const int a = e >= 2 * nf ? 2 : (e >= nf ? 1 : 0);
+            const int f = e - a * nf;
+            const float sa = a == 0 ? so[0] : (a == 1 ? so[1] : so[2]);
+            if (f >= 5 && sa > p.score_thr) {
+                const float approx = sa * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[k]));
+                if (approx > cut) {
+                    const float sc = sa * sigmoid_f(v[k]);
+                    if (sc > p.score_thr) {
+                        hit = true;
+                        const uint32_t id = (uint32_t)(box0 + a) * (uint32_t)p.C + (uint32_t)(f - 5);
+                        key[k] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(~id);
+                    }
+                }
+            }
+        }
+        mask[k] = __ballot(hit);
+        total += (uint32_t)__popcll(mask[k]);
+    }
+    if (total) {                              // ONE atomic per cell
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(p.counts + (size_t)n * COUNT_STRIDE, total);
+        base = __shfl(base, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((mask[k] >> lane) & 1ull) {
+                const uint32_t pos = base + (uint32_t)__popcll(mask[k] & ((1ull << lane) - 1ull));
+                if (pos < p.cap) keys[pos] = key[k];
+            }
+            base += (uint32_t)__popcll(mask[k]);
+        }
+    }
+    // box coordinates of the anchors that can have candidates (custom_layers.py:251-256)
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float t0 = value_at(i), t1 = value_at(nf + i), t2 = value_at(2 * nf + i);
+        t[i] = lane == 0 ? t0 : (lane == 1 ? t1 : t2);
+    }
+    if (lane < 3 && (lane == 0 ? so[0] : (lane == 1 ? so[1] : so[2])) > p.score_thr) {
+        const int row = rem / g, col = rem - row * g;
+        const float bx = ((sigmoid_f(t[0]) * p.xyscale[s]) - p.xyoff[s] + (float)col) * (float)p.stride[s];
+        const float by = ((sigmoid_f(t[1]) * p.xyscale[s]) - p.xyoff[s] + (float)row) * (float)p.stride[s];
+        const float bw = expf(t[2]) * p.anchors[(s * 3 + lane) * 2 + 0];
+        const float bh = expf(t[3]) * p.anchors[(s * 3 + lane) * 2 + 1];
+        float4 o;
+        o.x = (bx - bw / 2.0f) / p.img_size;
+        o.y = (by - bh / 2.0f) / p.img_size;
+        o.z = (bx + bw / 2.0f) / p.img_size;
+        o.w = (by + bh / 2.0f) / p.img_size;
+        *(float4*)(p.dboxes + ((int64_t)n * p.nbox + box0 + lane) * 4) = o;
     }
 }
 
@@ -133,7 +228,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
     // sh[0]=count in chunk, sh[1]=kept, sh[2]=remaining below cutoff, sh[3..4]=pivot lo/hi, sh[5]=need
 
     const int n = blockIdx.x, tid = threadIdx.x;
-    uint32_t cnt = p.counts[n];
+    uint32_t cnt = p.counts[(size_t)n * COUNT_STRIDE];
     if (cnt > p.cap) {
         if (tid == 0) atomicOr(p.status, 1u);
         cnt = p.cap;
@@ -285,9 +380,14 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
 size_t nms_lds_bytes(int max_total) { return (size_t)SORT_CAP * 24 + (size_t)max_total * (16 + 12) + 256 * 4 + 64; }
 
 int decode_launch(const DecodeK& k, hipStream_t stream) {
-    Y4_CHECK_HIP(hipMemsetAsync(k.counts, 0, sizeof(uint32_t) * k.N, stream));
-    const int64_t boxes = (int64_t)k.N * k.nbox;
-    hipLaunchKernelGGL(decode_kernel, dim3((int)((boxes + 255) / 256)), dim3(256), 0, stream, k);
+    Y4_CHECK_HIP(hipMemsetAsync(k.counts, 0, sizeof(uint32_t) * k.N * COUNT_STRIDE, stream));
+    if (3 * (5 + k.C) <= 256) {
+        const int64_t cells = (int64_t)k.N * k.cells_per_img;
+        hipLaunchKernelGGL(decode_cell_kernel, dim3((int)((cells + 3) / 4)), dim3(256), 0, stream, k);
+    } else {
+        const int64_t boxes = (int64_t)k.N * k.nbox;
+        hipLaunchKernelGGL(decode_kernel, dim3((int)((boxes + 255) / 256)), dim3(256), 0, stream, k);
+    }
     Y4_CHECK_HIP(hipGetLastError());
     return Y4_OK;
 }

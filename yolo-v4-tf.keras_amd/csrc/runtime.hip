@@ -244,7 +244,7 @@ void layout(y4_ctx& c) {
     c.dbox_off = off; off = align256(off + nb * c.nbox * 16);
     c.cand_cap = (uint32_t)c.nbox * (uint32_t)c.cfg.num_classes;         // worst case: exact for any input
     c.keys_off = off; off = align256(off + nb * (size_t)c.cand_cap * 8);
-    c.counts_off = off; off = align256(off + nb * 4);
+    c.counts_off = off; off = align256(off + nb * 4 * COUNT_STRIDE);
     c.status_off = off; off = align256(off + 256);
     c.scratch_off = off; off = align256(off + nb * (size_t)c.cfg.max_total * 28 + nb * 4);
     c.act_bytes = off;
