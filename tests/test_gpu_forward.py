@@ -152,6 +152,28 @@ def test_batch_rows_independent_of_batch_size():
     eng.close()
 
 
+def test_scheduling_knobs_do_not_change_results():
+    """Autotuned tiles, restored tiles and sub-batched early layers are speed knobs: outputs stay bit-identical."""
+    cfg, plan, ws, imgs, eng = _setup(160, 3, 3, "bf16", seed=4)
+    base = eng.predict(imgs, with_indices=True)
+    heads = eng.forward_heads(imgs)
+    tiles = eng.autotune(3, reps=1)
+    assert len(tiles) == 110 and tiles[0] == 0 and all(t > 0 for t in tiles[1:])
+    for a, b in zip(base, eng.predict(imgs, with_indices=True)):
+        assert np.array_equal(a, b)
+    eng.set_tiles([0] * 110)
+    eng.set_subbatch(2, 16)
+    for a, b in zip(heads, eng.forward_heads(imgs)):
+        assert np.array_equal(a, b)
+    for a, b in zip(base, eng.predict(imgs, with_indices=True)):
+        assert np.array_equal(a, b)
+    eng.set_subbatch(0)
+    eng.set_tiles(tiles)
+    for a, b in zip(base, eng.predict(imgs, with_indices=True)):
+        assert np.array_equal(a, b)
+    eng.close()
+
+
 def test_engine_fails_loudly():
     from yolo4hip import ext
     from yolo4hip.config import make_config
