@@ -103,13 +103,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
     constexpr int WPX = BM / WM, WCH = BN / WN;
     constexpr int MREP = WPX / 16, NREP = WCH / 16;
     constexpr int CPL = 4 * NREP;           // consecutive channels a lane owns
+    constexpr bool PHASED = (NST == 12);     // 2 LDS stages, two wave groups staggered by one of 4 phases per K-tile
+    constexpr int SN = PHASED ? 2 : NST;     // LDS stages
     constexpr int STAGE = (BM + BN) * BKB;
     constexpr int KSTEPS = BKB / 64;        // MFMA k-steps (4 chunks each) per tile
     static_assert(BM % 16 == 0 && (BN % RPI == 0 || (RPI % BN == 0 && (BN * CPR) % 64 == 0)), "tile rows vs rows-per-iteration");
     static_assert(MREP >= 1 && NREP >= 1, "wave tile");
     constexpr int LPT = A_IT + B_IT;        // LDS-DMA instructions a wave issues per stage
-    static_assert(NST >= 2 && NST <= 4 && (NST == 2 || (!B_PART && !A_PART)), "deep pipelines need uniform loads per wave");
-    static_assert((NST - 2) * LPT <= 63, "vmcnt field");
+    static_assert(SN >= 2 && SN <= 4 && (SN == 2 || !B_PART), "deep pipelines need uniform weight loads per wave");
+    static_assert((SN - 2) * LPT <= 63, "vmcnt field");
+    static_assert(!PHASED || (NT == 512 && KSTEPS == 2), "phased schedule: 8 waves, 128-byte K rows");
     using E = Elem<DT>;
     using T = typename E::type;
 
@@ -163,6 +166,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(p.wt, p.wt_bytes);
     const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);          // provably uniform -> SALU/M0 path
 
+    // wave-uniform: does this wave skip the (partial) last A iteration?  (rows r0 + (A_IT-1)*RPI >= BM)
+    const bool a_skip = A_PART && __builtin_amdgcn_readfirstlane(r0 + (A_IT - 1) * RPI >= BM ? 1 : 0) != 0;
     int ky = 0, kx = 0, c0b = 0, ktb = 0;          // staging cursor: tap, byte offset of c0, byte offset of k in the weights
     int a_vo[A_IT];
     auto set_tap = [&]() {
@@ -208,10 +213,67 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
 #pragma unroll
         for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const int nk = p.K / BK;
+    if constexpr (PHASED) {
+        // Staggered 4-phase schedule for one 8-wave workgroup per CU.  A K-tile is READ(k-step 0) | MMA | READ(k-step 1) |
+        // MMA with a workgroup barrier after every phase; waves 4-7 run ONE phase behind waves 0-3 (they take one
+        // extra barrier first, waves 0-3 one extra at the end), so while one group's 4 waves (one per SIMD) issue
+        // MFMAs the other group's 4 waves read their fragments from LDS: the matrix pipe and the LDS port are busy
+        // at the same time instead of alternately.  Stage hazards (2 LDS stages):
+        //   group 0 issues tile t+1's loads at the start of its tile t   (both groups have finished reading t-1),
+        //   group 1 issues tile t+2's loads at the start of its last MMA phase of tile t,
+        //   each wave waits for its own loads (vmcnt(0)) before the barrier that precedes the first read of them.
+        auto phase_barrier = [] {
+            asm volatile("s_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto wait_loads = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        const bool grp1 = __builtin_amdgcn_readfirstlane(wave >= 4 ? 1 : 0) != 0;
+        stage(0);
+        wait_loads();
+        phase_barrier();
+        if (grp1) {
+            if (nk > 1) stage(1);
+            phase_barrier();
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sx = lds_x + (kt & 1) * STAGE;
+            const char* sw = lds_w + (kt & 1) * STAGE;
+            u32x4 xf[MREP], wf[NREP];
+            if (!grp1 && kt + 1 < nk) stage((kt + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) xf[i] = *(const u32x4*)(sx + i * 16 * BKB + xo[0]);
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) wf[j] = *(const u32x4*)(sw + j * 16 * BKB + xo[0]);
+            phase_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc[i][j], wf[j], xf[i]);
+            __builtin_amdgcn_s_setprio(0);
+            phase_barrier();
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) xf[i] = *(const u32x4*)(sx + i * 16 * BKB + xo[1]);
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) wf[j] = *(const u32x4*)(sw + j * 16 * BKB + xo[1]);
+            if (grp1) wait_loads();
+            phase_barrier();
+            if (grp1 && kt + 2 < nk) stage(kt & 1);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc[i][j], wf[j], xf[i]);
+            __builtin_amdgcn_s_setprio(0);
+            if (!grp1) wait_loads();
+            phase_barrier();
+        }
+        if (!grp1) phase_barrier();
+    } else {
     // NST-stage ring: tiles kt+1 .. kt+NST-2 stay in flight (counted vmcnt, never drained in steady state)
     // while tile kt is consumed; ONE barrier per K-tile: it proves tile kt has landed for every wave and
     // that every wave is done reading the stage (tile kt-1's) that the next stage() call overwrites.
-    const int nk = p.K / BK;
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
         if (s < nk) stage(s);
@@ -219,7 +281,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
     for (int kt = 0; kt < nk; ++kt) {
         const int ahead = nk - 1 - kt;         // tiles issued after kt so far (capped at NST-2)
         if (NST == 2 || ahead == 0) wait_vmcnt_then_barrier<0>();
-        else if (NST == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT>();
+        else if (a_skip) {                     // this wave issues one load fewer per stage (partial last A iteration)
+            if (NST == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT - 1>();
+            else wait_vmcnt_then_barrier<2 * (LPT - 1)>();
+        } else if (NST == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT>();
         else wait_vmcnt_then_barrier<2 * LPT>();
         if (kt + NST - 1 < nk) stage(nxt);
         const char* sx = lds_x + cur * STAGE;
@@ -238,6 +303,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
 #pragma unroll
                 for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc[i][j], wf[j], xf[i]);
         }
+    }
     }
 
     // ---- epilogue: y = act(acc*scale + shift) (+ residual) -> NHWC slice store (optionally 2x2 replicated).
@@ -371,7 +437,10 @@ struct TileCfg {
     X(26, 144, 128, 1, 4, 128, 2) \
     X(27, 80, 128, 1, 4, 128, 2)  \
     X(28, 48, 128, 1, 4, 128, 2)  \
-    X(29, 112, 128, 1, 4, 128, 2)
+    X(29, 112, 128, 1, 4, 128, 2) \
+    X(30, 192, 256, 2, 4, 128, 12) \
+    X(31, 256, 256, 2, 4, 128, 12) \
+    X(32, 224, 256, 2, 4, 128, 12)
 
 #define Y4_TILE_ROW(id, bm, bn, wm, wn, bkb, nst) {bm, bn, wm, wn, bkb, nst},
 static const TileCfg kTiles[] = {Y4_TILES(Y4_TILE_ROW)};
@@ -381,7 +450,7 @@ int conv_tile_count() { return kNumTiles; }
 
 template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST>
 static int launch_cfg(const ConvK& k, hipStream_t stream) {
-    constexpr int lds = NST * (BM + BN) * BKB;
+    constexpr int lds = (NST == 12 ? 2 : NST) * (BM + BN) * BKB;
     auto kern = conv_igemm_kernel<DT, BM, BN, WM, WN, BKB, NST>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
