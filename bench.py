@@ -112,7 +112,7 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
-    eng.timing_begin(args.steps)
+    eng.timing_begin(args.steps, coarse=not args.per_op)    # 7 events per step (conv runs timed as a whole) unless --per-op
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.predict_device(imgs, outs)
@@ -126,7 +126,7 @@ def main():
         n_img = args.batch * world * args.steps
         conv_ms = sum(ms for name, ms in ops if name.startswith("c") and name != "c0")
         conv_flops = sum(c.flops_per_image for c in plan.convs[1:]) * (hi - lo)
-        launches = sum(1 for name, _ in ops if name.startswith("c") and name != "c0")
+        launches = sum(1 for name, _ in ops if name.startswith("c") and name != "c0")   # fused CSP pairs count once
         other = {name: ms for name, ms in ops if not name.startswith("c") or name == "c0"}
         total_ms = sum(ms for _, ms in ops)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0

@@ -141,8 +141,10 @@ int y4_set_subbatch(y4_handle h, int images, int last_conv);
 
 /* Live per-op timing of the calls in between: while a session is open, each y4_predict (up to max_steps of
  * them) records a HIP event on its stream after every op, without synchronising.  y4_timing_end
- * synchronises the stream and returns the mean device time per op in ms ('c1'.., 'spp', 'decode', 'nms'). */
-int y4_timing_begin(y4_handle h, int max_steps);
+ * synchronises the stream and returns the mean device time per op in ms ('c1'.., 'spp', 'decode', 'nms').
+ * coarse != 0: events only where the op kind changes (stem | run of convs | spp | run of convs | decode | nms);
+ * each run's time is reported under its first op, the others read 0 -- 7 events per step instead of 115. */
+int y4_timing_begin(y4_handle h, int max_steps, int coarse);
 int y4_timing_end(y4_handle h, float* op_ms_mean, char* names, int cap, int* n_ops, int* steps_recorded,
                   void* stream);
 

@@ -81,7 +81,9 @@ struct y4_ctx {
     // timing session (y4_timing_begin/end): per-op HIP events recorded by y4_predict
     std::vector<hipEvent_t> t_events;
     int t_max_steps = 0, t_steps = 0, t_per_step = 0, t_n = 0;
-    std::vector<int> t_slot_op;       // op index measured by each event slot of a step
+    std::vector<int> t_slot_op;       // op index credited with each event interval of a step
+    std::vector<char> t_rec;          // per launch: record an event after it?
+    bool t_coarse = false;            // events only where the op kind changes (stem | conv run | spp | conv run | decode | nms)
     // sub-batching: ops [0, sub_last_op] run over `sub_images` images at a time (keeps the large early
     // activations of one sub-batch resident in the 256 MiB Infinity Cache between producer and consumer)
     int sub_images = 0, sub_last_op = -1;
@@ -539,7 +541,20 @@ static int predict_impl(y4_handle h, const float* imgs, int n, float* boxes, flo
     if (ev && h->t_steps == 0) {
         h->t_n = n;
         h->t_slot_op.clear();
-        for (const Launch& l : sched) h->t_slot_op.push_back(l.op);
+        h->t_rec.assign(sched.size(), 1);
+        int seg_first = sched.empty() ? 0 : sched[0].op;
+        for (size_t k = 0; k < sched.size(); ++k) {
+            const bool last = k + 1 == sched.size();
+            const bool boundary = last || h->ops[sched[k + 1].op].kind != h->ops[sched[k].op].kind;
+            if (!h->t_coarse) {
+                h->t_slot_op.push_back(sched[k].op);
+            } else if (boundary) {
+                h->t_slot_op.push_back(seg_first);           // the whole run of same-kind ops is credited to its first op
+                if (!last) seg_first = sched[k + 1].op;
+            } else {
+                h->t_rec[k] = 0;
+            }
+        }
         h->t_slot_op.push_back((int)h->ops.size());
         h->t_slot_op.push_back((int)h->ops.size() + 1);
     }
@@ -547,9 +562,10 @@ static int predict_impl(y4_handle h, const float* imgs, int n, float* boxes, flo
     h->t_recorded_this_call = ev != nullptr;
     int i = 0;
     if (ev) Y4_CHECK_HIP(hipEventRecord(ev[0], s));
-    for (const Launch& l : sched) {
+    for (size_t k = 0; k < sched.size(); ++k) {
+        const Launch& l = sched[k];
         if (int r = run_op(h, h->ops[l.op], imgs, l.cnt, s, l.img0)) return r;
-        if (ev) Y4_CHECK_HIP(hipEventRecord(ev[++i], s));
+        if (ev && h->t_rec[k]) Y4_CHECK_HIP(hipEventRecord(ev[++i], s));
     }
     for (int stage = 1; stage <= 2; ++stage) {
         if (int r = run_decode_nms(h, n, h->cfg.iou_threshold, h->cfg.score_threshold, boxes, scores, classes, valid,
@@ -643,10 +659,11 @@ int y4_get_tiles(y4_handle h, int32_t* tiles, int cap) {
     return Y4_OK;
 }
 
-int y4_timing_begin(y4_handle h, int max_steps) {
+int y4_timing_begin(y4_handle h, int max_steps, int coarse) {
     if (int r = check_handle(h)) return r;
     Y4_REQUIRE(max_steps >= 1 && max_steps <= 4096, Y4_EINVAL, "y4_timing_begin: max_steps %d", max_steps);
     Y4_REQUIRE(h->t_max_steps == 0, Y4_ESTATE, "a timing session is already open");
+    h->t_coarse = coarse != 0;
     {
         std::vector<Launch> sched;
         build_schedule(h, h->cfg.max_batch, sched);
@@ -704,7 +721,7 @@ int y4_timing_end(y4_handle h, float* op_ms_mean, char* names, int cap, int* n_o
 int y4_profile(y4_handle h, const float* imgs, int n, float* op_ms, char* names, int cap, int* n_ops, void* stream) {
     if (int r = check_ready(h, n)) return r;
     Y4_REQUIRE(imgs && op_ms && n_ops, Y4_EINVAL, "y4_profile: null argument");
-    if (int r = y4_timing_begin(h, 1)) return r;
+    if (int r = y4_timing_begin(h, 1, 0)) return r;
     float* boxes = (float*)(h->act + h->scratch_off);
     float* scores = boxes + (size_t)n * h->cfg.max_total * 4;
     float* classes = scores + (size_t)n * h->cfg.max_total;

@@ -226,8 +226,8 @@ class Engine:
         activations); 0 turns it off.  Results are unchanged."""
         ext.check(self.lib.y4_set_subbatch(self.handle, int(images), int(last_conv)))
 
-    def timing_begin(self, max_steps):
-        ext.check(self.lib.y4_timing_begin(self.handle, int(max_steps)))
+    def timing_begin(self, max_steps, coarse=False):
+        ext.check(self.lib.y4_timing_begin(self.handle, int(max_steps), int(bool(coarse))))
 
     def timing_end(self):
         """-> ([(op name, mean ms)], steps recorded); synchronises the current stream."""
