@@ -105,6 +105,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
     constexpr int CPL = 4 * NREP;           // consecutive channels a lane owns
     constexpr bool PHASED = (NST == 12);     // 2 LDS stages, two wave groups staggered by one of 4 phases per K-tile
     constexpr int SN = PHASED ? 2 : NST;     // LDS stages
+    constexpr bool PREFRAG = true;           // all fragments of a K-tile are read before its first MFMA (measured: never slower)
     constexpr int STAGE = (BM + BN) * BKB;
     constexpr int KSTEPS = BKB / 64;        // MFMA k-steps (4 chunks each) per tile
     static_assert(BM % 16 == 0 && (BN % RPI == 0 || (RPI % BN == 0 && (BN * CPR) % 64 == 0)), "tile rows vs rows-per-iteration");
@@ -275,22 +276,42 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
     // while tile kt is consumed; ONE barrier per K-tile: it proves tile kt has landed for every wave and
     // that every wave is done reading the stage (tile kt-1's) that the next stage() call overwrites.
 #pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
+    for (int s = 0; s < SN - 1; ++s)
         if (s < nk) stage(s);
-    int cur = 0, nxt = NST - 1;
+    int cur = 0, nxt = SN - 1;
     for (int kt = 0; kt < nk; ++kt) {
         const int ahead = nk - 1 - kt;         // tiles issued after kt so far (capped at NST-2)
-        if (NST == 2 || ahead == 0) wait_vmcnt_then_barrier<0>();
+        if (SN == 2 || ahead == 0) wait_vmcnt_then_barrier<0>();
         else if (a_skip) {                     // this wave issues one load fewer per stage (partial last A iteration)
-            if (NST == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT - 1>();
+            if (SN == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT - 1>();
             else wait_vmcnt_then_barrier<2 * (LPT - 1)>();
-        } else if (NST == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT>();
+        } else if (SN == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT>();
         else wait_vmcnt_then_barrier<2 * LPT>();
-        if (kt + NST - 1 < nk) stage(nxt);
+        if (kt + SN - 1 < nk) stage(nxt);
         const char* sx = lds_x + cur * STAGE;
         const char* sw = lds_w + cur * STAGE;
-        cur = cur + 1 == NST ? 0 : cur + 1;
-        nxt = nxt + 1 == NST ? 0 : nxt + 1;
+        cur = cur + 1 == SN ? 0 : cur + 1;
+        nxt = nxt + 1 == SN ? 0 : nxt + 1;
+        if constexpr (PREFRAG) {
+            // issue every fragment read of the K-tile first: the reads of k-step 1 then fly behind the MFMAs of
+            // k-step 0 (the compiler's counted lgkmcnt waits keep the order), at the price of a second fragment set
+            u32x4 xf[KSTEPS][MREP], wf[KSTEPS][NREP];
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) xf[kk][i] = *(const u32x4*)(sx + i * 16 * BKB + xo[kk]);
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) wf[kk][j] = *(const u32x4*)(sw + j * 16 * BKB + xo[kk]);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk)
+#pragma unroll
+                for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                    for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc[i][j], wf[kk][j], xf[kk][i]);
+            __builtin_amdgcn_s_setprio(0);
+        } else
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             u32x4 xf[MREP], wf[NREP];
