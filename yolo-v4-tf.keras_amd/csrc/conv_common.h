@@ -1,0 +1,177 @@
+// conv_common.h -- pieces shared by the implicit-GEMM conv kernels (conv_igemm.hip, conv_halo.hip).
+#pragma once
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace y4 {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+struct ConvK {
+    const char* in;
+    const char* wt;
+    const float* scale;
+    const float* shift;
+    const char* res;
+    char* out;
+    const char* zero;
+    int N, H, W, Cin, Ho, Wo, cout_store, M, K;
+    int in_cstride, in_coff, out_cstride, out_coff, res_cstride, res_coff;
+    int ksize, stride, pad, act, upsample, out_f32;
+    int grid_m, grid_n;
+    unsigned in_bytes, wt_bytes;   // buffer-descriptor extents (bounds-checked loads)
+    FastDiv div_howo, div_wo;      // m -> (n, ho, wo) without integer division
+    FastDiv div_gridn;
+    char* out2;                    // channels >= split go to this view (fused CSP route + main-in pair)
+    int out2_cstride, out2_coff, split;
+};
+
+template <int CPR> __device__ __forceinline__ int swz(int row) {
+    return CPR == 8 ? (row & 7) : ((row >> 1) & 3);
+}
+
+template <int DT> struct Mma;
+template <> struct Mma<Y4_F32> {
+    static __device__ __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[j]), __uint_as_float(x[j]), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<Y4_BF16> {
+    static __device__ __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x),
+                                                      acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<Y4_F16> {
+    static __device__ __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x),
+                                                     acc, 0, 0, 0);
+    }
+};
+
+// buffer_load_dwordx4 ... lds: 16 bytes per lane from (descriptor base + voffset + soffset) to LDS at
+// (wave-uniform lds_dst + lane*16); lanes whose voffset is outside the descriptor's extent receive zeros.
+// Kept in a NON-template function: inside a template the target builtin is checked at instantiation time
+// for the host pass too, which silently drops the kernel's host stub.
+__device__ __forceinline__ void buffer_load16_lds(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt_then_barrier() {
+    // counted wait for this wave's own LDS-DMA loads, then the workgroup barrier; one asm statement with a
+    // "memory" clobber so that neither the compiler's loads/stores nor its own waitcnt logic move across it
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+
+// ---- epilogue shared by the conv kernels: y = act(acc*scale + shift) (+ residual) -> NHWC slice store
+// (optionally 2x2 replicated, optionally split over two output views).  `mrow` is this lane's output pixel index
+// for fragment 0 (fragment i is 16 pixels further), pixels >= m_limit are not stored, `chb` is the lane's first
+// channel.  FULL (block-uniform): no per-row / per-chunk predicates at all.
+template <int DT, int MREP, int NREP, int ACT, bool FULL>
+__device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[MREP][NREP], const float* sc,
+                                                   const float* sh, int mrow, int m_limit, int chb) {
+    using E = Elem<DT>;
+    using T = typename E::type;
+    constexpr int EPC = E::EPC;
+    constexpr int CPL = 4 * NREP;
+    constexpr bool FAST = (DT != Y4_F32);
+    const int HoWo = p.Ho * p.Wo;
+    // split output: a lane's CPL channels never straddle `split` (both are multiples of CPL)
+    const bool second = p.split > 0 && chb >= p.split;
+    char* const out_ptr = second ? p.out2 : p.out;
+    const int out_cs = second ? p.out2_cstride : p.out_cstride;
+    const int out_co = (second ? p.out2_coff - p.split : p.out_coff) + chb;
+    const T* const res_base = (const T*)p.res + (int64_t)mrow * p.res_cstride + p.res_coff + chb;
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = mrow + i * 16;
+        if (!FULL && m >= m_limit) continue;
+        float v[CPL];
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = j * 4 + r;
+                v[c] = apply_act_t<FAST, ACT>(fmaf(acc[i][j][r], sc[c], sh[c]));
+            }
+        if (p.res) {
+            const T* rp = res_base + (int64_t)(i * 16) * p.res_cstride;
+#pragma unroll
+            for (int c = 0; c < CPL; c += EPC) {
+                if (FULL || chb + c < p.cout_store) {
+                    float rv[EPC];
+                    E::load_chunk(rp + c, rv);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[c + e] += rv[e];
+                }
+            }
+        }
+        int64_t pix[4];
+        int npix = 1;
+        if (p.upsample) {
+            const int n = (int)fastdiv((uint32_t)m, p.div_howo), rem = m - n * HoWo;
+            const int ho = (int)fastdiv((uint32_t)rem, p.div_wo), wo = rem - ho * p.Wo;
+            const int W2 = 2 * p.Wo;
+            const int64_t base = ((int64_t)n * 2 * p.Ho + 2 * ho) * W2 + 2 * wo;
+            pix[0] = base; pix[1] = base + 1; pix[2] = base + W2; pix[3] = base + W2 + 1;
+            npix = 4;
+        } else {
+            pix[0] = m;
+        }
+        if (p.out_f32) {
+            for (int u = 0; u < npix; ++u) {
+                float* op = (float*)out_ptr + pix[u] * out_cs + out_co;
+#pragma unroll
+                for (int c = 0; c < CPL; c += 4)
+                    if (FULL || chb + c < p.cout_store) Elem<Y4_F32>::store_chunk(op + c, v + c);
+            }
+        } else {
+            u32x4 packed[CPL / EPC];
+#pragma unroll
+            for (int c = 0; c < CPL; c += EPC) E::store_chunk(&packed[c / EPC], v + c);
+            for (int u = 0; u < npix; ++u) {
+                T* op = (T*)out_ptr + pix[u] * out_cs + out_co;
+#pragma unroll
+                for (int c = 0; c < CPL; c += EPC)
+                    if (FULL || chb + c < p.cout_store) *(u32x4*)(op + c) = packed[c / EPC];
+            }
+        }
+    }
+}
+
+template <int DT, int MREP, int NREP>
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP][NREP], int mrow, int m_limit, int chb,
+                                              bool full) {
+    constexpr int CPL = 4 * NREP;
+    float sc[CPL], sh[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c += 4) {
+        const f32x4 s4 = *(const f32x4*)(p.scale + chb + c);
+        const f32x4 h4 = *(const f32x4*)(p.shift + chb + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[c + e] = s4[e]; sh[c + e] = h4[e]; }
+    }
+    // the activation and the mask mode are compile-time inside; one uniform switch outside the pixel loop
+    if (p.act == Y4_ACT_MISH) {
+        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, true>(p, acc, sc, sh, mrow, m_limit, chb);
+        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, false>(p, acc, sc, sh, mrow, m_limit, chb);
+    } else if (p.act == Y4_ACT_LEAKY) {
+        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LEAKY, true>(p, acc, sc, sh, mrow, m_limit, chb);
+        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LEAKY, false>(p, acc, sc, sh, mrow, m_limit, chb);
+    } else {
+        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, true>(p, acc, sc, sh, mrow, m_limit, chb);
+        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, false>(p, acc, sc, sh, mrow, m_limit, chb);
+    }
+}
+
+}  // namespace y4

@@ -16,77 +16,9 @@
 // ds_read_b128 lane group hits 16 distinct slots; global_load_lds writes LDS lane-linearly, so the
 // swizzle is applied to the per-lane SOURCE address and again on the fragment read (same involution).
 // Pipeline: 2 LDS stages, one barrier per K-tile: loads of tile t+1 fly during the MFMAs of tile t.
-#include <type_traits>
-
-#include "kernels.h"
+#include "conv_common.h"
 
 namespace y4 {
-
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-
-struct ConvK {
-    const char* in;
-    const char* wt;
-    const float* scale;
-    const float* shift;
-    const char* res;
-    char* out;
-    const char* zero;
-    int N, H, W, Cin, Ho, Wo, cout_store, M, K;
-    int in_cstride, in_coff, out_cstride, out_coff, res_cstride, res_coff;
-    int ksize, stride, pad, act, upsample, out_f32;
-    int grid_m, grid_n;
-    unsigned in_bytes, wt_bytes;   // buffer-descriptor extents (bounds-checked loads)
-    FastDiv div_howo, div_wo;      // m -> (n, ho, wo) without integer division
-    FastDiv div_gridn;
-    char* out2;                    // channels >= split go to this view (fused CSP route + main-in pair)
-    int out2_cstride, out2_coff, split;
-};
-
-template <int CPR> __device__ __forceinline__ int swz(int row) {
-    return CPR == 8 ? (row & 7) : ((row >> 1) & 3);
-}
-
-template <int DT> struct Mma;
-template <> struct Mma<Y4_F32> {
-    static __device__ __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[j]), __uint_as_float(x[j]), acc, 0, 0, 0);
-    }
-};
-template <> struct Mma<Y4_BF16> {
-    static __device__ __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x),
-                                                      acc, 0, 0, 0);
-    }
-};
-template <> struct Mma<Y4_F16> {
-    static __device__ __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x),
-                                                     acc, 0, 0, 0);
-    }
-};
-
-// buffer_load_dwordx4 ... lds: 16 bytes per lane from (descriptor base + voffset + soffset) to LDS at
-// (wave-uniform lds_dst + lane*16); lanes whose voffset is outside the descriptor's extent receive zeros.
-// Kept in a NON-template function: inside a template the target builtin is checked at instantiation time
-// for the host pass too, which silently drops the kernel's host stub.
-__device__ __forceinline__ void buffer_load16_lds(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, int soffset) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt_then_barrier() {
-    // counted wait for this wave's own LDS-DMA loads, then the workgroup barrier; one asm statement with a
-    // "memory" clobber so that neither the compiler's loads/stores nor its own waitcnt logic move across it
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-}
 
 template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p) {
@@ -327,100 +259,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
     }
     }
 
-    // ---- epilogue: y = act(acc*scale + shift) (+ residual) -> NHWC slice store (optionally 2x2 replicated).
-    // The activation is a compile-time tag inside (one uniform switch outside the pixel loop); conversions
-    // use the packed hardware converts (Elem<DT>::store_chunk).
+    // ---- epilogue (conv_common.h): scale/shift, activation, residual, packed converts, slice / upsampled / split store
     const int chb = n0 + wn * WCH + fg * CPL;       // this lane's first channel
-    float sc[CPL], sh[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; c += 4) {
-        const f32x4 s4 = *(const f32x4*)(p.scale + chb + c);
-        const f32x4 h4 = *(const f32x4*)(p.shift + chb + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { sc[c + e] = s4[e]; sh[c + e] = h4[e]; }
-    }
-    constexpr bool FAST = (DT != Y4_F32);
-    // FULL (block-uniform): every pixel row of the tile is < M and every channel chunk is stored -> no per-row /
-    // per-chunk predicates at all; partial tiles (last M tile, the heads' last channel tile) take the masked path.
-    auto epilogue = [&](auto act_tag, auto full_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
-        constexpr bool FULL = decltype(full_tag)::value;
-        const int mrow = m0 + wm * WPX + frow;
-        // split output: a lane's CPL channels never straddle `split` (both are multiples of CPL)
-        const bool second = p.split > 0 && chb >= p.split;
-        char* const out_ptr = second ? p.out2 : p.out;
-        const int out_cs = second ? p.out2_cstride : p.out_cstride;
-        const int out_co = (second ? p.out2_coff - p.split : p.out_coff) + chb;
-        const T* const res_base = (const T*)p.res + (int64_t)mrow * p.res_cstride + p.res_coff + chb;
-#pragma unroll
-        for (int i = 0; i < MREP; ++i) {
-            const int m = mrow + i * 16;
-            if (!FULL && m >= p.M) continue;
-            float v[CPL];
-#pragma unroll
-            for (int j = 0; j < NREP; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = j * 4 + r;
-                    v[c] = apply_act_t<FAST, ACT>(fmaf(acc[i][j][r], sc[c], sh[c]));
-                }
-            if (p.res) {
-                const T* rp = res_base + (int64_t)(i * 16) * p.res_cstride;
-#pragma unroll
-                for (int c = 0; c < CPL; c += EPC) {
-                    if (FULL || chb + c < p.cout_store) {
-                        float rv[EPC];
-                        E::load_chunk(rp + c, rv);
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e) v[c + e] += rv[e];
-                    }
-                }
-            }
-            int64_t pix[4];
-            int npix = 1;
-            if (p.upsample) {
-                const int n = (int)fastdiv((uint32_t)m, p.div_howo), rem = m - n * HoWo;
-                const int ho = (int)fastdiv((uint32_t)rem, p.div_wo), wo = rem - ho * p.Wo;
-                const int W2 = 2 * p.Wo;
-                const int64_t base = ((int64_t)n * 2 * p.Ho + 2 * ho) * W2 + 2 * wo;
-                pix[0] = base; pix[1] = base + 1; pix[2] = base + W2; pix[3] = base + W2 + 1;
-                npix = 4;
-            } else {
-                pix[0] = m;
-            }
-            if (p.out_f32) {
-                for (int u = 0; u < npix; ++u) {
-                    float* op = (float*)out_ptr + pix[u] * out_cs + out_co;
-#pragma unroll
-                    for (int c = 0; c < CPL; c += 4)
-                        if (FULL || chb + c < p.cout_store) Elem<Y4_F32>::store_chunk(op + c, v + c);
-                }
-            } else {
-                u32x4 packed[CPL / EPC];
-#pragma unroll
-                for (int c = 0; c < CPL; c += EPC) E::store_chunk(&packed[c / EPC], v + c);
-                for (int u = 0; u < npix; ++u) {
-                    T* op = (T*)out_ptr + pix[u] * out_cs + out_co;
-#pragma unroll
-                    for (int c = 0; c < CPL; c += EPC)
-                        if (FULL || chb + c < p.cout_store) *(u32x4*)(op + c) = packed[c / EPC];
-                }
-            }
-        }
-    };
     const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.cout_store);
-    using TT = std::true_type;
-    using FF = std::false_type;
-    if (p.act == Y4_ACT_MISH) {
-        if (full) epilogue(std::integral_constant<int, Y4_ACT_MISH>{}, TT{});
-        else epilogue(std::integral_constant<int, Y4_ACT_MISH>{}, FF{});
-    } else if (p.act == Y4_ACT_LEAKY) {
-        if (full) epilogue(std::integral_constant<int, Y4_ACT_LEAKY>{}, TT{});
-        else epilogue(std::integral_constant<int, Y4_ACT_LEAKY>{}, FF{});
-    } else {
-        if (full) epilogue(std::integral_constant<int, Y4_ACT_LINEAR>{}, TT{});
-        else epilogue(std::integral_constant<int, Y4_ACT_LINEAR>{}, FF{});
-    }
+    conv_epilogue<DT, MREP, NREP>(p, acc, m0 + wm * WPX + frow, p.M, chb, full);
 }
 
 // ------------------------------------------------------------------------------------------- launch
