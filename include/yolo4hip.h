@@ -189,6 +189,10 @@ int y4_pack_stem_weights(const float* w_oihw_dev, float* wk_dev, int cout, void*
 int y4_stem_conv(int dtype, const float* imgs_dev, int n, int h, int w, const float* wk_dev,
                  const float* scale, const float* shift, int cout, int act, void* out_dev, int out_cstride,
                  int out_coff, void* stream);
+/* Device-side Yolov4.preprocess_img (reference models.py:95-98: cv2.resize INTER_LINEAR stretch, then /255.):
+ * uint8 RGB image [h,w,3] -> float32 [out_h,out_w,3] in [0,1], one image slot of the batch tensor y4_forward takes.
+ * Saves the 4x fatter float32 host->device copy and the host-side float64 tensor. */
+int y4_preprocess_u8(const uint8_t* img_dev, int h, int w, float* out_dev, int out_h, int out_w, void* stream);
 /* SPP (custom_layers.py:130-134): x = buf[..., 3c:4c] -> buf[..., 0:c]=maxpool13, [c:2c]=maxpool9,
  * [2c:3c]=maxpool5 (stride 1, 'same'), buf is [n,side,side,4c] */
 int y4_spp(int dtype, void* buf_dev, int n, int side, int c, void* stream);

@@ -14,6 +14,7 @@ int pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw
 int stem_conv_launch(int dtype, const float* imgs, int n, int h, int w, const float* wk, const float* scale,
                      const float* shift, int cout, int act, void* out, int out_cstride, int out_coff, hipStream_t stream);
 int pack_stem_weights(const float* w_oihw, float* wk, int cout, hipStream_t stream);
+int preprocess_u8_launch(const uint8_t* img, int h, int w, float* out, int H, int W, hipStream_t stream);
 int spp_launch(int dtype, void* buf, int n, int side, int c, hipStream_t stream);
 int view_to_f32_launch(int dtype, const void* src, float* dst, int64_t pixels, int cstride, int coff, int c,
                        hipStream_t stream);

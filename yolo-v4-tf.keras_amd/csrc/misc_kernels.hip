@@ -370,6 +370,54 @@ int spp_launch(int dtype, void* buf, int n, int side, int c, hipStream_t stream)
     return Y4_EINVAL;
 }
 
+// ------------------------------------------------------------------------------ image pre-processing
+// Yolov4.preprocess_img (reference models.py:95-98): cv2.resize(img, (W,H)) [INTER_LINEAR, plain stretch] then
+// img / 255.  uint8 RGB [h,w,3] on device -> float32 [H,W,3] in [0,1].  Restates OpenCV's uint8 fixed-point
+// bilinear scheme (half-pixel centres, 11-bit coefficients, two rounding shifts) exactly like the host version
+// yolo4hip/prepost.py: resize_bilinear, so both paths give identical floats.
+__device__ __forceinline__ void lin_coeff(int d, int dst, int src, int& s0, int& s1, int& a0, int& a1) {
+    const double scale = (double)src / (double)dst;
+    double f = ((double)d + 0.5) * scale - 0.5;
+    int s = (int)floor(f);
+    float fr = (float)(f - (double)s);
+    if (s < 0) { fr = 0.f; s = 0; }
+    if (s >= src - 1) { fr = 0.f; s = src - 1; }
+    s0 = s;
+    s1 = s + 1 < src ? s + 1 : src - 1;
+    a1 = (int)rintf(fr * 2048.0f);
+    a0 = (int)rintf((1.0f - fr) * 2048.0f);
+}
+
+__global__ void preprocess_u8_kernel(const uint8_t* __restrict__ img, int h, int w, float* __restrict__ out, int H, int W) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i - y * W;
+    int x0, x1, ax0, ax1, y0, y1, ay0, ay1;
+    lin_coeff(x, W, w, x0, x1, ax0, ax1);
+    lin_coeff(y, H, h, y0, y1, ay0, ay1);
+    const bool same = (h == H && w == W);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int v;
+        if (same) {
+            v = img[(y * w + x) * 3 + c];
+        } else {
+            const int top = img[(y0 * w + x0) * 3 + c] * ax0 + img[(y0 * w + x1) * 3 + c] * ax1;   // x2048
+            const int bot = img[(y1 * w + x0) * 3 + c] * ax0 + img[(y1 * w + x1) * 3 + c] * ax1;
+            v = (((ay0 * (top >> 4)) >> 16) + ((ay1 * (bot >> 4)) >> 16) + 2) >> 2;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        out[i * 3 + c] = (float)((double)v / 255.0);
+    }
+}
+
+int preprocess_u8_launch(const uint8_t* img, int h, int w, float* out, int H, int W, hipStream_t stream) {
+    Y4_REQUIRE(img && out && h > 0 && w > 0 && H > 0 && W > 0, Y4_EINVAL, "preprocess_u8: bad argument");
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3((H * W + 255) / 256), dim3(256), 0, stream, img, h, w, out, H, W);
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
 // ----------------------------------------------------------------------- view -> dense float32 copy
 template <int DT>
 __global__ void view_to_f32_kernel(const typename Elem<DT>::type* __restrict__ src, float* __restrict__ dst,

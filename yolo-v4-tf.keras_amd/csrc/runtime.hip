@@ -767,6 +767,10 @@ int y4_stem_conv(int dtype, const float* imgs_dev, int n, int h, int w, const fl
                             out_coff, (hipStream_t)stream);
 }
 
+int y4_preprocess_u8(const uint8_t* img_dev, int h, int w, float* out_dev, int out_h, int out_w, void* stream) {
+    return preprocess_u8_launch(img_dev, h, w, out_dev, out_h, out_w, (hipStream_t)stream);
+}
+
 int y4_spp(int dtype, void* buf_dev, int n, int side, int c, void* stream) {
     return spp_launch(dtype, buf_dev, n, side, c, (hipStream_t)stream);
 }

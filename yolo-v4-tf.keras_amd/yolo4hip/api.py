@@ -34,7 +34,7 @@ class _KerasLikeModel:
 
 class Yolov4(object):
     def __init__(self, weight_path=None, class_name_path='coco_classes.txt', config=yolo_config, *,
-                 dtype='f32', max_batch=32, synth_seed=0, device=None):
+                 dtype='f32', max_batch=32, synth_seed=0, device=None, device_preprocess=True):
         assert config['img_size'][0] == config['img_size'][1], 'not support yet'
         assert config['img_size'][0] % config['strides'][-1] == 0, 'must be a multiple of last stride'
         self.class_names = [line.strip() for line in open(class_name_path).readlines()]
@@ -51,6 +51,7 @@ class Yolov4(object):
         self.config = config
         assert self.num_classes > 0, 'no classes detected!'
         self._dtype, self._max_batch, self._synth_seed, self._device = dtype, max_batch, synth_seed, device
+        self._device_preprocess = device_preprocess
         self.build_model(load_pretrained=True if self.weight_path else False)
 
     def build_model(self, load_pretrained=True):
@@ -86,8 +87,12 @@ class Yolov4(object):
     def predict_img(self, raw_img, random_color=True, plot_img=True, figsize=(10, 10), show_text=True,
                     return_output=False):
         print('img shape: ', raw_img.shape)
-        img = self.preprocess_img(raw_img)
-        imgs = np.expand_dims(img, axis=0)
+        if self._device_preprocess and getattr(raw_img, 'dtype', None) == np.uint8:
+            # same arithmetic as preprocess_img (tests: bit-identical), on the GPU: the uint8 image crosses PCIe
+            imgs = self.engine.preprocess_u8(np.ascontiguousarray(raw_img))
+        else:
+            img = self.preprocess_img(raw_img)
+            imgs = np.expand_dims(img, axis=0)
         pred_output = self.inference_model.predict(imgs)
         detections = prepost.get_detection_data(img=raw_img, model_outputs=pred_output, class_names=self.class_names)
         output_img = prepost.draw_bbox(raw_img, detections, cmap=self.class_color, random_color=random_color,
@@ -100,6 +105,49 @@ class Yolov4(object):
     def predict(self, img_path, random_color=True, plot_img=True, figsize=(10, 10), show_text=True):
         raw_img = prepost.imread_rgb(img_path)
         return self.predict_img(raw_img, random_color, plot_img, figsize, show_text)
+
+    # ---- reference models.py:129-139: annotation lines "path x1,y1,x2,y2,cls ..." -> one "<name> x1 y1 x2 y2" file each
+    def export_gt(self, annotation_path, gt_folder_path):
+        with open(annotation_path) as fh:
+            for line in fh:
+                fields = line.split(' ')
+                stem = fields[0].split(os.sep)[-1].split('.')[0]
+                with open(os.path.join(gt_folder_path, stem + '.txt'), 'w') as out:
+                    for obj in fields[1:]:
+                        x_min, y_min, x_max, y_max, class_id = [float(v) for v in obj.strip().split(',')]
+                        out.write(f'{self.class_names[int(class_id)]} {x_min} {y_min} {x_max} {y_max}\n')
+
+    # ---- reference models.py:141-179: the reference's only BATCHED caller of inference_model.predict.
+    # One "<class> <score> <x1> <y1> <x2> <y2>" line per detection, coordinates in raw-image pixels.  Like the
+    # reference it feeds cv2.imread's BGR channel order (no flip, unlike predict()).
+    def export_prediction(self, annotation_path, pred_folder_path, img_folder_path, bs=2):
+        with open(annotation_path) as fh:
+            img_paths = [os.path.join(img_folder_path, line.split(' ')[0].split(os.sep)[-1].strip()) for line in fh]
+        try:
+            from tqdm import tqdm
+        except ImportError:                      # progress bar only
+            def tqdm(it):
+                return it
+        for start in tqdm(range(0, len(img_paths), bs)):
+            paths = img_paths[start:start + bs]
+            raws = [prepost.imread_rgb(pth)[:, :, ::-1] for pth in paths]
+            if self._device_preprocess:
+                imgs = self.engine.preprocess_u8([np.ascontiguousarray(r) for r in raws])
+            else:
+                imgs = np.stack([self.preprocess_img(r) for r in raws])
+            b_boxes, b_scores, b_classes, b_valid = self.inference_model.predict(imgs)
+            for k, pth in enumerate(paths):
+                nb = int(b_valid[k])
+                h, w = raws[k].shape[:2]
+                boxes = b_boxes[k, :nb]
+                boxes[:, [0, 2]] *= w                 # the returned arrays are writable host copies
+                boxes[:, [1, 3]] *= h
+                names = [self.class_names[int(c)] for c in b_classes[k, :nb]]
+                stem = pth.split(os.sep)[-1].split('.')[0]
+                with open(os.path.join(pred_folder_path, stem + '.txt'), 'w') as out:
+                    for j in range(nb):
+                        b = boxes[j]
+                        out.write(f'{names[j]} {b_scores[k, j]} {b[0]} {b[1]} {b[2]} {b[3]}\n')
 
     # ---- reference models.py:509-514 (note: no BGR->RGB flip there; cv2.imread order is BGR)
     def predict_raw(self, img_path):

@@ -116,6 +116,24 @@ class Engine:
             raise ValueError(f"expected images of shape [N,{self.img_size},{self.img_size},3], got {tuple(t.shape)}")
         return t.contiguous()
 
+    def preprocess_u8(self, raw_imgs):
+        """Device-side `Yolov4.preprocess_img` (reference models.py:95-98) for one uint8 RGB image [h,w,3] or a list
+        of them (any sizes): returns the float32 cuda tensor [n,S,S,3] that `forward_device` / `predict` take."""
+        torch = self.torch
+        if isinstance(raw_imgs, np.ndarray) and raw_imgs.ndim == 3:
+            raw_imgs = [raw_imgs]
+        out = torch.empty((len(raw_imgs), self.img_size, self.img_size, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            for i, im in enumerate(raw_imgs):
+                a = np.ascontiguousarray(im)
+                if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+                    raise ValueError(f"expected uint8 [h,w,3] images, got {a.dtype} {a.shape}")
+                d = torch.from_numpy(a).to(self.device)
+                ext.check(self.lib.y4_preprocess_u8(ext.ptr(d), a.shape[0], a.shape[1], ext.ptr(out[i]), self.img_size,
+                                                    self.img_size, ext.stream_ptr()))
+            torch.cuda.current_stream().synchronize()       # the uint8 staging tensors may be freed now
+        return out
+
     def forward_device(self, imgs_dev):
         n = imgs_dev.shape[0]
         with self.torch.cuda.device(self.device):

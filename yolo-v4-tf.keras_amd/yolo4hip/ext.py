@@ -82,6 +82,7 @@ SYMBOLS = {
     "y4_conv_tile_count": (_I, []),
     "y4_pack_stem_weights": (_I, [_VP, _VP, _I, _VP]),
     "y4_stem_conv": (_I, [_I, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _I, _VP]),
+    "y4_preprocess_u8": (_I, [_VP, _I, _I, _VP, _I, _I, _VP]),
     "y4_spp": (_I, [_I, _VP, _I, _I, _I, _VP]),
 }
 
