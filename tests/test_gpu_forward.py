@@ -174,6 +174,24 @@ def test_scheduling_knobs_do_not_change_results():
     eng.close()
 
 
+def test_packed_weight_cache_roundtrip(tmp_path):
+    from yolo4hip.config import make_config
+    from yolo4hip.engine import Engine
+    cfg, plan, ws, imgs, eng = _setup(96, 2, 2, "f16", seed=6)
+    want = eng.forward_heads(imgs)
+    path = str(tmp_path / "packed.bin")
+    eng.save_packed(path)
+    eng2 = Engine(2, make_config(96), max_batch=2, dtype="f16")
+    eng2.load_packed(path)
+    for a, b in zip(want, eng2.forward_heads(imgs)):
+        assert np.array_equal(a, b)
+    eng3 = Engine(3, make_config(96), max_batch=2, dtype="f16")
+    with pytest.raises(ValueError):
+        eng3.load_packed(path)
+    for e in (eng, eng2, eng3):
+        e.close()
+
+
 def test_engine_fails_loudly():
     from yolo4hip import ext
     from yolo4hip.config import make_config

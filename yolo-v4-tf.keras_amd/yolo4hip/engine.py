@@ -89,6 +89,34 @@ class Engine:
             ext.check(self.lib.y4_pack_weights(self.handle, ext.ptr(flat), flat.numel(), ext.stream_ptr()))
             torch.cuda.current_stream().synchronize()      # `flat` may be freed after this returns
 
+    # packed-weight cache: the packed workspace is a pure function of (weights, classes, dtype,
+    # library layout version), so it can be written once and re-loaded without re-reading / re-packing the
+    # 258 MB Darknet file.
+    def save_packed(self, path):
+        import json
+        meta = {"version": self.lib.y4_version().decode(), "num_classes": self.num_classes, "dtype": self.dtype,
+                "wts_bytes": self.wts_bytes}
+        blob = self.wts.cpu().numpy()
+        with open(path, "wb") as f:
+            head = json.dumps(meta).encode()
+            f.write(len(head).to_bytes(8, "little")); f.write(head); blob.tofile(f)
+
+    def load_packed(self, path):
+        import json
+        with open(path, "rb") as f:
+            n = int.from_bytes(f.read(8), "little")
+            meta = json.loads(f.read(n).decode())
+            want = {"version": self.lib.y4_version().decode(), "num_classes": self.num_classes, "dtype": self.dtype,
+                    "wts_bytes": self.wts_bytes}
+            if meta != want:
+                raise ValueError(f"packed-weight cache {path} was written for {meta}, this engine needs {want}")
+            blob = np.fromfile(f, dtype=np.uint8)
+        if blob.size != self.wts_bytes:
+            raise ValueError(f"packed-weight cache {path} is truncated: {blob.size} of {self.wts_bytes} bytes")
+        self.wts.copy_(self.torch.from_numpy(blob).to(self.device))
+        self.torch.cuda.synchronize(self.device)
+        self.adopt_packed()
+
     def adopt_packed(self):
         ext.check(self.lib.y4_adopt_packed_weights(self.handle))
 
