@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristic instead of measuring")
+    ap.add_argument("--tune-reps", type=int, default=3)
     ap.add_argument("--save-tiles", default=None, help="write the autotuned per-layer tile ids to this JSON file")
     ap.add_argument("--load-tiles", default=None, help="use tile ids from this JSON file instead of autotuning")
     ap.add_argument("--subbatch", type=int, default=0, help="images per sub-batch for the early layers (0 = whole batch)")
@@ -100,7 +101,7 @@ def main():
         eng.set_tiles(tiles)
     elif not args.no_autotune:
         eng.predict_device(imgs, outs)                        # real activations in the workspace
-        tiles = eng.autotune(hi - lo)                         # untimed, one-off: fastest tile per layer (bit-identical results)
+        tiles = eng.autotune(hi - lo, reps=args.tune_reps)                         # untimed, one-off: fastest tile per layer (bit-identical results)
     else:
         tiles = None
     if args.save_tiles and rank == 0 and tiles:
