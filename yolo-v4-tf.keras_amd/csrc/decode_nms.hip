@@ -215,6 +215,7 @@ __device__ __forceinline__ float iou_tf(const float4 a, const float4 b) {
     return inter / (area_a + area_b - inter);
 }
 
+template <int KSLOT>   // kept boxes per lane of the scanning wave: 64 * KSLOT >= max_total
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
     extern __shared__ __attribute__((aligned(16))) char nsm[];
     unsigned long long* skey = (unsigned long long*)nsm;                  // SORT_CAP
@@ -315,39 +316,61 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
         // ---- gather the chunk's boxes into LDS
         for (uint32_t i = tid; i < m; i += NMS_THREADS) {
             const uint32_t id = ~(uint32_t)(skey[i] & 0xffffffffull);
-            sbox[i] = *(const float4*)(gb + (int64_t)(id / (uint32_t)p.C) * 4);
+            sbox[i] = *(const float4*)(gb + (int64_t)fastdiv(id, p.div_c) * 4);
         }
         __syncthreads();
-        // ---- greedy pass (wave 0)
+        // ---- greedy pass (wave 0).  Lane l keeps kept boxes l, l+64, ... (up to KSLOT) in REGISTERS, so a candidate
+        // costs two broadcast LDS reads (its key and box, prefetched one candidate ahead) plus <= KSLOT IoUs per lane
+        // and one ballot; the LDS copies (kbox/kcls/...) are only written, for the output stage.
         if (tid < 64) {
             int kept = (int)sh[1];
+            float4 rbox[KSLOT];
+            int rcls[KSLOT];
+#pragma unroll
+            for (int k = 0; k < KSLOT; ++k) {               // reload after a chunk boundary (rare)
+                const int j = tid + 64 * k;
+                rcls[k] = j < kept ? kcls[j] : -1;
+                rbox[k] = j < kept ? kbox[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const bool cap_binds = p.max_per_class < p.max_total;
+            unsigned long long key = m ? skey[0] : 0ull;
+            float4 cb = m ? sbox[0] : make_float4(0.f, 0.f, 0.f, 0.f);
             for (uint32_t t = 0; t < m && kept < p.max_total; ++t) {
-                const unsigned long long key = skey[t];
+                const unsigned long long key_n = t + 1 < m ? skey[t + 1] : 0ull;     // prefetch the next candidate
+                const float4 cb_n = t + 1 < m ? sbox[t + 1] : cb;
                 const uint32_t id = ~(uint32_t)(key & 0xffffffffull);
-                const int cls = (int)(id % (uint32_t)p.C);
-                const float4 cb = sbox[t];
+                const uint32_t bi = fastdiv(id, p.div_c);
+                const int cls = (int)(id - bi * (uint32_t)p.C);
                 bool sup = false;
                 int same = 0;
-                for (int j = tid; j < kept; j += 64) {
-                    if (kcls[j] == cls) {
+                const int nslot = (kept + 63) >> 6;
+#pragma unroll
+                for (int k = 0; k < KSLOT; ++k) {
+                    if (k < nslot && rcls[k] == cls) {
                         ++same;
-                        sup = sup || (iou_tf(cb, kbox[j]) > p.iou_thr);
+                        sup = sup || (iou_tf(cb, rbox[k]) > p.iou_thr);
                     }
                 }
-                const bool any_sup = __ballot(sup) != 0ull;
-                for (int o = 32; o > 0; o >>= 1) same += __shfl_xor(same, o);
-                if (!any_sup && same < p.max_per_class) {
+                bool keep = __ballot(sup) == 0ull;
+                if (keep && cap_binds) {
+                    for (int o = 32; o > 0; o >>= 1) same += __shfl_xor(same, o);
+                    keep = same < p.max_per_class;
+                }
+                if (keep) {
+                    const int slot = kept >> 6, owner = kept & 63;
+#pragma unroll
+                    for (int k = 0; k < KSLOT; ++k)
+                        if (k == slot && tid == owner) { rbox[k] = cb; rcls[k] = cls; }
                     if (tid == 0) {
                         kbox[kept] = cb;
                         kcls[kept] = cls;
                         kscore[kept] = __uint_as_float((uint32_t)(key >> 32));
-                        kidx[kept] = (int)(id / (uint32_t)p.C);
+                        kidx[kept] = (int)bi;
                     }
                     ++kept;
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_s_waitcnt(0);
-                    __builtin_amdgcn_wave_barrier();
                 }
+                key = key_n;
+                cb = cb_n;
             }
             if (tid == 0) sh[1] = (uint32_t)kept;
         }
@@ -394,13 +417,17 @@ int decode_launch(const DecodeK& k, hipStream_t stream) {
 
 int nms_launch(const NmsK& k, hipStream_t stream) {
     const size_t lds = nms_lds_bytes(k.max_total);
+    Y4_REQUIRE(lds <= 160 * 1024 && k.max_total <= 1024, Y4_EINVAL, "nms: max_total %d needs %zu bytes of LDS", k.max_total, lds);
     static bool attr_set = false;
     if (!attr_set) {
-        Y4_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        Y4_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        Y4_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        Y4_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    Y4_REQUIRE(lds <= 160 * 1024, Y4_EINVAL, "nms: max_total %d needs %zu bytes of LDS", k.max_total, lds);
-    hipLaunchKernelGGL(nms_kernel, dim3(k.N), dim3(NMS_THREADS), lds, stream, k);
+    if (k.max_total <= 128) hipLaunchKernelGGL(nms_kernel<2>, dim3(k.N), dim3(NMS_THREADS), lds, stream, k);
+    else if (k.max_total <= 256) hipLaunchKernelGGL(nms_kernel<4>, dim3(k.N), dim3(NMS_THREADS), lds, stream, k);
+    else hipLaunchKernelGGL(nms_kernel<16>, dim3(k.N), dim3(NMS_THREADS), lds, stream, k);
     Y4_CHECK_HIP(hipGetLastError());
     return Y4_OK;
 }

@@ -51,6 +51,7 @@ struct NmsK {
     int32_t* out_valid;              // [N]
     int32_t* out_idx;                // [N, max_total] or null
     uint32_t* status;                // [1] bit0: candidate list overflowed its capacity
+    FastDiv div_c;                   // id -> (box, class) without integer division (ids < 2^31 checked at y4_create)
 };
 int decode_launch(const DecodeK& k, hipStream_t stream);
 int nms_launch(const NmsK& k, hipStream_t stream);

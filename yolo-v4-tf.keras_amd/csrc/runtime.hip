@@ -350,6 +350,7 @@ int run_decode_nms(y4_handle h, int n, float iou_thr, float score_thr, float* bo
         k.max_total = cfg.max_total; k.max_per_class = cfg.max_per_class; k.iou_thr = iou_thr;
         k.out_boxes = boxes; k.out_scores = scores; k.out_classes = classes; k.out_valid = valid; k.out_idx = kept_idx;
         k.status = (uint32_t*)(h->act + h->status_off);
+        k.div_c = fastdiv_make((uint32_t)cfg.num_classes);
         if (int r = nms_launch(k, s)) return r;
     }
     return Y4_OK;
@@ -381,7 +382,7 @@ int y4_create(const y4_config* cfg, y4_handle* out) {
     c->hcs = (int)round_up(3 * (cfg->num_classes + 5), 8);
     c->nbox = 0;
     for (int i = 0; i < 3; ++i) { const int g = c->S / cfg->strides[i]; c->nbox += 3 * g * g; }
-    if ((int64_t)c->nbox * cfg->num_classes >= (1ll << 32)) {
+    if ((int64_t)c->nbox * cfg->num_classes >= (1ll << 31)) {
         delete c;
         set_error("num_boxes*num_classes overflows the 32-bit candidate id");
         return Y4_EINVAL;
