@@ -8,7 +8,7 @@
 A step = one y4_predict over one batch of 32 images already resident in HBM (float32 NHWC in [0,1]; the
 PCIe-inclusive rate is noted in DESIGN.md, it is never `value`).  Timed region: barrier +
 torch.cuda.synchronize() on both sides, MAX over ranks, whole-job images / time.
-`roofline` is for the dominant kernel family (conv_igemm_kernel, convs 1..109): algorithmic conv FLOPs of
+`roofline` is for the dominant kernel family (conv_igemm_kernel: convs 2..109, or 1..109 with --no-stem-fusion): algorithmic conv FLOPs of
 one step / its summed per-launch device time, measured with HIP events recorded on the launch stream
 inside the timed region (y4_timing_begin/end).  `cpu_baseline` times the oracle (a torch-CPU/NumPy
 restatement; the reference's tf.keras path cannot run here) on a bounded sample on rank 0 at N=1.
@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--load-tiles", default=None, help="use tile ids from this JSON file instead of autotuning")
     ap.add_argument("--subbatch", type=int, default=0, help="images per sub-batch for the early layers (0 = whole batch)")
     ap.add_argument("--sub-last-conv", type=int, default=16)
+    ap.add_argument("--no-stem-fusion", action="store_true", help="run convs 0 and 1 as two kernels (c0 through HBM)")
     ap.add_argument("--per-op", action="store_true", help="also print the per-op time table to stderr")
     args = ap.parse_args()
 
@@ -96,6 +97,10 @@ def main():
     outs = eng.alloc_outputs(hi - lo)
     if args.subbatch > 0:
         eng.set_subbatch(args.subbatch, args.sub_last_conv)
+    fused_stem = args.dtype != "f32" and args.size <= 640 and not args.no_stem_fusion
+    if fused_stem:
+        eng.set_stem_fusion(True)          # convs 0+1 in one kernel; conv 1 then leaves the conv_igemm family below
+    first_conv = 2 if fused_stem else 1
     if args.load_tiles:
         tiles = json.load(open(args.load_tiles))["tiles"]
         eng.set_tiles(tiles)
@@ -126,7 +131,7 @@ def main():
     if rank == 0:
         n_img = args.batch * world * args.steps
         conv_ms = sum(ms for name, ms in ops if name.startswith("c") and name != "c0")
-        conv_flops = sum(c.flops_per_image for c in plan.convs[1:]) * (hi - lo)
+        conv_flops = sum(c.flops_per_image for c in plan.convs[first_conv:]) * (hi - lo)
         launches = sum(1 for name, _ in ops if name.startswith("c") and name != "c0")   # fused CSP pairs count once
         other = {name: ms for name, ms in ops if not name.startswith("c") or name == "c0"}
         total_ms = sum(ms for _, ms in ops)
@@ -146,10 +151,10 @@ def main():
                        "sharding": f"batch split over {world} rank(s), no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
-                         "kernel": "conv_igemm_kernel (convs 1..109, %d launches/step)" % launches,
+                         "kernel": "conv_igemm_kernel (convs %d..109, %d launches/step)" % (first_conv, launches - (first_conv - 1)),
                          "flops_per_step": conv_flops, "kernel_ms_per_step": round(conv_ms, 4),
                          "timed_steps": nrec},
-            "breakdown_ms_per_step": {"conv_igemm": round(conv_ms, 4), "stem_c0": round(other.get("c0", 0.0), 4),
+            "breakdown_ms_per_step": {"conv_igemm": round(conv_ms, 4), ("stem_c0+c1_fused" if fused_stem else "stem_c0"): round(other.get("c0", 0.0), 4),
                                       "spp": round(other.get("spp", 0.0), 4),
                                       "decode": round(other.get("decode", 0.0), 4),
                                       "nms": round(other.get("nms", 0.0), 4), "sum_of_ops": round(total_ms, 4),

@@ -139,6 +139,12 @@ int y4_set_tiles(y4_handle h, const int32_t* tiles, int count);
  * 256 MiB Infinity Cache when their consumer runs.  images <= 0 turns it off. */
 int y4_set_subbatch(y4_handle h, int images, int last_conv);
 
+/* Scheduling knob (16-bit dtypes, img_size <= 640; results unchanged): run convs 0 and 1 (reference
+ * custom_layers.py:101-102) as one kernel that keeps conv 0's output -- the largest tensor of the network -- in LDS
+ * instead of writing it to HBM and reading it back.  While on, y4_get_conv_output(0) fails with Y4_ESTATE and the
+ * profile reports the pair under 'c0' ('c1' reads 0).  Y4_EINVAL if the dtype / size is not supported. */
+int y4_set_stem_fusion(y4_handle h, int on);
+
 /* Live per-op timing of the calls in between: while a session is open, each y4_predict (up to max_steps of
  * them) records a HIP event on its stream after every op, without synchronising.  y4_timing_end
  * synchronises the stream and returns the mean device time per op in ms ('c1'.., 'spp', 'decode', 'nms').

@@ -174,6 +174,46 @@ def test_scheduling_knobs_do_not_change_results():
     eng.close()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("size,n", [(160, 3), (416, 2), (608, 1), (640, 1)])
+def test_stem_fusion_is_bit_identical(dtype, size, n):
+    """convs 0+1 as one kernel (conv 0's output kept in LDS): same MFMA products summed in the same order as the two
+    separate kernels, so conv 1's output, the heads and the detections must be bit-identical -- including the
+    top/left zero padding of the stride-2 conv, the image border rows and a sub-batched schedule."""
+    import yolo4hip.ext as ext
+    cfg, plan, ws, imgs, eng = _setup(size, 3, n, dtype, seed=5)
+    heads = eng.forward_heads(imgs)
+    c1 = eng.conv_output(1, n)
+    c0 = eng.conv_output(0, n)
+    base = eng.predict(imgs, with_indices=True)
+    eng.set_stem_fusion(True)
+    for a, b in zip(heads, eng.forward_heads(imgs)):
+        assert np.array_equal(a, b)
+    assert np.array_equal(c1, eng.conv_output(1, n))
+    with pytest.raises(ext.Y4Error):
+        eng.conv_output(0, n)
+    if n > 1:
+        eng.set_subbatch(1, 16)
+        for a, b in zip(base, eng.predict(imgs, with_indices=True)):
+            assert np.array_equal(a, b)
+        eng.set_subbatch(0)
+    eng.autotune(n, reps=1)
+    for a, b in zip(base, eng.predict(imgs, with_indices=True)):
+        assert np.array_equal(a, b)
+    eng.set_stem_fusion(False)
+    eng.forward_heads(imgs)
+    assert np.array_equal(c0, eng.conv_output(0, n))
+    eng.close()
+
+
+def test_stem_fusion_rejected_where_unsupported():
+    import yolo4hip.ext as ext
+    cfg, plan, ws, imgs, eng = _setup(160, 3, 1, "f32")
+    with pytest.raises(ext.Y4Error):
+        eng.set_stem_fusion(True)
+    eng.close()
+
+
 def test_packed_weight_cache_roundtrip(tmp_path):
     from yolo4hip.config import make_config
     from yolo4hip.engine import Engine

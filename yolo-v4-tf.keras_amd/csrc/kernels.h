@@ -21,6 +21,12 @@ int view_to_f32_launch(int dtype, const void* src, float* dst, int64_t pixels, i
 int f32_to_view_launch(const float* src, float* dst, int64_t pixels, int cstride, int c, hipStream_t stream);
 int fold_bn_launch(const float* rec, float* scale, float* shift, int cout, int cout_pad, int has_bn, hipStream_t stream);
 
+// stem_down.hip: convs 0+1 fused (16-bit dtypes), c0 stays in LDS
+bool stem_down_supported(int dtype, int S);
+int stem_down_launch(int dtype, const float* imgs, int n, int S, const void* stem_wk, const float* s0_scale,
+                     const float* s0_shift, int act0, const void* w1_packed, const float* s1_scale, const float* s1_shift,
+                     int act1, void* out, int out_cstride, int out_coff, hipStream_t stream);
+
 // decode_nms.hip
 // Per-image candidate counters are spaced one per 256 bytes: packed into one cache line, the ~10^3 appends per
 // image of a whole batch serialise on a single L2 line (measured: decode 195 us -> see DESIGN.md).

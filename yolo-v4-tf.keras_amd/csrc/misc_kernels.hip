@@ -3,6 +3,7 @@
 //   SPP max-pools + concat (reference custom_layers.py:130-134)
 //   view -> dense float32 copies (what Keras returns from yolo_model.predict, reference models.py:514)
 #include "kernels.h"
+#include "stem_common.h"
 
 namespace y4 {
 
@@ -83,21 +84,12 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane & 15, g = lane >> 4;
     const u32x4 wf0 = wfrag[lane], wf1 = wfrag[64 + lane];
-    // this lane's 8 taps k = 8g .. 8g+7  ->  (dy, dx, float offset), fixed for the whole kernel
-    int dyx[8], toff[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = 8 * g + e;
-        const int ky = k / 9, j = k - ky * 9, kx = j / 3, ci = j - kx * 3;
-        const bool real = k < 27;
-        dyx[e] = real ? (((ky - 1) & 0xffff) << 16) | ((kx - 1) & 0xffff) : 0x40004000;     // pad taps never validate
-        toff[e] = ((ky - 1) * W + (kx - 1)) * 3 + ci;
-    }
     float sc[8], sh[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) { sc[c] = scale[g * 8 + c]; sh[c] = shift[g * 8 + c]; }
     const int64_t total = (int64_t)N * H * W;
     const int HW = H * W;
+    const bool tile_rows = (W & 15) == 0;                        // a 16-pixel tile never straddles two rows
     int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * tiles_per_wave * 16;
     constexpr bool FAST = true;
     for (int t = 0; t < tiles_per_wave; ++t, p0 += 16) {
@@ -108,14 +100,13 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         const int n = (int)fastdiv(pp, div_hw);
         const int rem = (int)pp - n * HW;
         const int y = (int)fastdiv((uint32_t)rem, div_w), x = rem - y * W;
-        const float* base = img + (int64_t)pp * 3;
+        // wave-uniform: the 16 pixels are one run of a row (W % 16 == 0) away from the image border
+        const int y0 = __builtin_amdgcn_readfirstlane(y), x0 = __builtin_amdgcn_readfirstlane(x);
+        const bool interior = tile_rows && p0 + 16 <= total && y0 >= 1 && y0 <= H - 2 && x0 >= 1 && x0 + 16 <= W - 1;
+        const float* imgn = img + (int64_t)n * HW * 3;
         float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int dy = (short)(dyx[e] >> 16), dx = (short)(dyx[e] & 0xffff);
-            const bool ok = (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
-            v[e] = ok ? base[toff[e]] : 0.f;
-        }
+        if (interior) stem_gather<false>(imgn, y, x, H, W, g, v);
+        else stem_gather<true>(imgn, y, x, H, W, g, v);
         u32x4 xf;
         E::store_chunk(&xf, v);
         stem_f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -142,7 +133,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
 
 // Darknet (cout,3,3,3) -> (a) [(ky*3+kx)*3+ci][cout] float table for the fp32 stem kernel at wk[0..27*cout),
 // (b) at byte 4096 the bf16 and at byte 6144 the fp16 MFMA weight-fragment tables [2 frags][64 lanes][8]:
-//     fragment jn, lane l holds row i = l&15 = g'*4 + r'  <->  channel g'*8 + jn*4 + r', taps k = 8*(l>>4) .. +7
+//     fragment jn, lane l holds row i = l&15 = g'*4 + r'  <->  channel g'*8 + jn*4 + r', K slots 8*(l>>4) .. +7
+//     in the order of stem_common.h
 __global__ void pack_stem_kernel(const float* __restrict__ w_oihw, float* __restrict__ wk, int cout) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 27 * cout) {
@@ -154,11 +146,12 @@ __global__ void pack_stem_kernel(const float* __restrict__ w_oihw, float* __rest
         const int e = i & 7, l = (i >> 3) & 63, jn = i >> 9;
         const int row = l & 15, gq = row >> 2, rr = row & 3;
         const int ch = gq * 8 + jn * 4 + rr;
-        const int k = 8 * (l >> 4) + e;
+        int ky, j;
+        stem_k_slot(l >> 4, e, ky, j);                  // K layout of stem_common.h
         float v = 0.f;
-        if (k < 27) {
-            const int ci = k % 3, tap = k / 3;
-            v = w_oihw[(ch * 3 + ci) * 9 + tap];
+        if (ky >= 0) {
+            const int kx = j / 3, ci = j - kx * 3;
+            v = w_oihw[(ch * 3 + ci) * 9 + ky * 3 + kx];
         }
         ((uint16_t*)((char*)wk + 4096))[i] = Elem<Y4_BF16>::st(v);
         ((_Float16*)((char*)wk + 6144))[i] = Elem<Y4_F16>::st(v);

@@ -87,6 +87,8 @@ struct y4_ctx {
     // sub-batching: ops [0, sub_last_op] run over `sub_images` images at a time (keeps the large early
     // activations of one sub-batch resident in the 256 MiB Infinity Cache between producer and consumer)
     int sub_images = 0, sub_last_op = -1;
+    // convs 0+1 as one kernel (stem_down.hip): op 0 launches it into op 1's output view, op 1 becomes a no-op
+    bool fuse_stem = false;
     bool t_recorded_this_call = false;
 };
 
@@ -300,6 +302,15 @@ int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s, i
     const Layer& L = h->layers[op.conv];
     const float* scale = (const float*)(h->wts + L.scale_off);
     const float* shift = (const float*)(h->wts + L.shift_off);
+    if (op.kind == OP_STEM && h->fuse_stem) {
+        const Op& o1 = h->ops[1];
+        const Layer& L1 = h->layers[1];
+        return stem_down_launch(h->cfg.dtype, imgs ? imgs + (size_t)img0 * h->S * h->S * 3 : imgs, n, h->S,
+                                h->wts + L.w_off, scale, shift, L.d.act, h->wts + L1.w_off,
+                                (const float*)(h->wts + L1.scale_off), (const float*)(h->wts + L1.shift_off), L1.d.act,
+                                buf_ptr(h, o1.out, img0), o1.out.cstride, o1.out.coff, s);
+    }
+    if (h->fuse_stem && op.kind == OP_CONV && op.conv == 1) return Y4_OK;
     if (op.kind == OP_STEM)
         return stem_conv_launch(h->cfg.dtype, imgs ? imgs + (size_t)img0 * h->S * h->S * 3 : imgs, n, h->S, h->S,
                                 (const float*)(h->wts + L.w_off), scale, shift, L.d.cout, L.d.act,
@@ -511,6 +522,7 @@ int y4_get_conv_output(y4_handle h, int conv_idx, int n, float* out, size_t out_
     if (int r = check_ready(h, n)) return r;
     for (const Op& op : h->ops) {
         if (op.kind == OP_SPP || (op.conv != conv_idx && op.conv2 != conv_idx)) continue;
+        Y4_REQUIRE(!(h->fuse_stem && conv_idx == 0), Y4_ESTATE, "conv 0 is not materialised while stem fusion is on");
         const View& v = op.conv == conv_idx ? op.out : op.out2;
         const int64_t px = (int64_t)n * v.side * v.side;   // for an upsampling conv: the upsampled tensor
         Y4_REQUIRE((int64_t)out_floats >= px * v.c, Y4_EINVAL, "output buffer too small: %zu < %lld", out_floats,
@@ -601,7 +613,7 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
     const int ntiles = conv_tile_count();
     for (int oi = 0; oi < (int)h->ops.size(); ++oi) {
         Op& op = h->ops[oi];
-        if (op.kind != OP_CONV) continue;
+        if (op.kind != OP_CONV || (h->fuse_stem && op.conv == 1)) continue;
         const int ne = (h->sub_images > 0 && oi <= h->sub_last_op && n > h->sub_images) ? h->sub_images : n;
         float best = 1e30f;
         int best_tile = 0;
@@ -645,6 +657,21 @@ int y4_set_subbatch(y4_handle h, int images, int last_conv) {
     Y4_REQUIRE(last_op >= 0, Y4_EINVAL, "y4_set_subbatch: no conv %d", last_conv);
     h->sub_images = images;
     h->sub_last_op = last_op;
+    return Y4_OK;
+}
+
+int y4_set_stem_fusion(y4_handle h, int on) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(h->t_max_steps == 0, Y4_ESTATE, "y4_set_stem_fusion: a timing session is open");
+    if (on) {
+        const bool shape_ok = h->ops.size() > 1 && h->ops[0].kind == OP_STEM && h->ops[1].kind == OP_CONV &&
+                              h->ops[1].conv == 1 && h->ops[1].conv2 < 0 && !h->ops[1].has_res &&
+                              h->layers[0].d.cout == 32 && h->layers[1].d.cout == 64 && h->layers[1].d.ksize == 3 &&
+                              h->layers[1].d.stride == 2;
+        Y4_REQUIRE(shape_ok && stem_down_supported(h->cfg.dtype, h->S), Y4_EINVAL,
+                   "y4_set_stem_fusion: needs a 16-bit dtype and img_size <= 640 (dtype %d, img_size %d)", h->cfg.dtype, h->S);
+    }
+    h->fuse_stem = on != 0;
     return Y4_OK;
 }
 

@@ -1,0 +1,51 @@
+// stem_common.h -- the MFMA stem's K layout, shared by stem_mfma_kernel (misc_kernels.hip), the fused convs 0+1
+// kernel (stem_down.hip) and pack_stem_kernel.
+// The 3x3x3 patch of pixel (y, x) is three runs of 9 consecutive floats in the NHWC image, one per row, starting
+// at pixel x-1.  K = 27 is padded to the MFMA's 32 as four lane groups of 8:
+//   group g < 3 : row y+g-1, floats 0..7 of its run (pixels x-1 and x, channels 0 and 1 of pixel x+1)
+//                 -> two 16-byte loads from one address per lane instead of eight scattered dword gathers
+//   group 3     : float 8 of the runs of rows y-1, y, y+1 (channel 2 of pixel x+1), then five zeros.
+#pragma once
+#include "common.h"
+
+namespace y4 {
+
+// K slot (g, e) -> (ky, j = kx*3 + ci), or ky = -1 for the zero padding.  Host and device.
+__host__ __device__ inline void stem_k_slot(int g, int e, int& ky, int& j) {
+    if (g < 3) { ky = g; j = e; }
+    else if (e < 3) { ky = e; j = 8; }
+    else { ky = -1; j = 0; }
+}
+
+// This lane's 8 K values for pixel (y, x) of the image at `img` (H x W x 3 floats).
+// EDGE = false: rows y-1..y+1 and columns x-1..x+1 are inside the image for every lane of the wave.
+template <bool EDGE>
+__device__ __forceinline__ void stem_gather(const float* __restrict__ img, int y, int x, int H, int W, int g, float v[8]) {
+    if (!EDGE) {
+        if (g < 3) {
+            const float* p = img + ((y + g - 1) * W + x - 1) * 3;
+            f32x4_t a, b;
+            __builtin_memcpy(&a, p, 16);
+            __builtin_memcpy(&b, p + 4, 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+        } else {
+            const float* p = img + ((y - 1) * W + x + 1) * 3 + 2;
+            v[0] = p[0]; v[1] = p[W * 3]; v[2] = p[2 * W * 3];
+#pragma unroll
+            for (int e = 3; e < 8; ++e) v[e] = 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int ky, j;
+            stem_k_slot(g, e, ky, j);
+            const int kx = j / 3, ci = j - kx * 3;
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            const bool ok = ky >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            v[e] = ok ? img[(yy * W + xx) * 3 + ci] : 0.f;
+        }
+    }
+}
+
+}  // namespace y4

@@ -1,0 +1,286 @@
+// stem_down.hip -- convs 0 and 1 of the plan as ONE kernel (16-bit paths):
+//   c0 = LeakyReLU(BN(conv3x3 s1 'same', 3 -> 32))            reference custom_layers.py:101
+//   c1 = LeakyReLU(BN(ZeroPad((1,0),(1,0)) + conv3x3 s2 'valid', 32 -> 64))   reference custom_layers.py:102, :9-12
+// Unfused, c0 is the largest tensor of the network (608^2 x 32 per image): writing it and reading it back is
+// ~1.5 GB of HBM traffic per 32 images for 0.5 % of the FLOPs.  Here a 1024-thread workgroup owns one OUTPUT ROW (n, ho) of c1:
+//   1. the c1 weights (64 x 288) are staged into LDS once (buffer_load ... lds),
+//   2. the three c0 rows 2ho-1 .. 2ho+1 it needs are COMPUTED into LDS with the MFMA stem (image patches loaded from
+//      global memory into registers in the K layout of stem_common.h), BN + LeakyReLU applied, stored as 16-bit,
+//   3. the stride-2 3x3 conv runs out of LDS: 9 taps x (Wo/16) pixel fragments x 4 channel fragments of MFMAs,
+//   4. BN + LeakyReLU, 16-byte NHWC stores.
+// c0 never exists in HBM.  Each c0 row is computed by the two output rows that use it (1.5x stem recompute, a few
+// hundred cheap MFMAs).  LDS image of the c0 strip: [3 rows][2 column-parity planes][Wo+1 slots][64 B]; splitting
+// even and odd columns into planes turns the stride-2 tap walk into unit-stride slot reads (conflict-free with the
+// usual XOR swizzle), and slot 0 of the odd plane is the zero column left of the image.
+#include "conv_common.h"
+#include "stem_common.h"
+
+namespace y4 {
+
+struct StemDownK {
+    const float* img;            // [N, S, S, 3] float32
+    const u32x4* stem_frag;      // [2][64] 16-byte weight fragments of the stem (see pack_stem_kernel)
+    const float* s0_scale;       // [32]
+    const float* s0_shift;
+    const char* w1;              // packed c1 weights [cout_pad][9][32] (16-bit)
+    const float* s1_scale;       // [64..]
+    const float* s1_shift;
+    char* out;                   // c1 view
+    int out_cstride, out_coff;
+    int N, S, act0, act1;
+    unsigned w1_bytes;
+};
+
+constexpr int SD_WAVES = 16, SD_WM = 8, SD_WN = 2;      // 1024 threads: the block is alone on its CU (LDS), so it
+                                                        // brings its own latency hiding
+constexpr int SD_UNROLL = 4;                            // stem tiles whose gathers are in flight together
+
+static __device__ __forceinline__ int sd_swz(int row) { return (row >> 1) & 3; }
+
+template <int DT, int MFW>     // MFW = max pixel fragments per wave row: ceil((Wo/16) / SD_WM)
+__global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDownK p) {
+    using E = Elem<DT>;
+    using T = typename E::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = p.S, Wo = S >> 1, PW = Wo + 1;
+    const int MF = Wo >> 4;                                   // pixel fragments per output row
+    char* const lds_w = smem;                                 // [9 taps][64 rows][64 B]
+    char* const lds_s = smem + 9 * 64 * 64;                   // [3 rows][2 planes][PW slots][64 B]
+    const int n = blockIdx.x / Wo, ho = blockIdx.x - n * Wo;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane & 15, g = lane >> 4;
+
+    // ---- 1. c1 weights -> LDS.  LDS row (tap*64 + pr), pr = jn*16 + i, holds channel g'*16 + jn*4 + r'
+    //         (i = g'*4 + r'), so that a lane's 16 accumulator values are 16 consecutive channels.
+    {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.w1, p.w1_bytes);
+        for (int u = wave; u < 9 * 4; u += SD_WAVES) {        // unit = 16 rows = 1024 B = one wave-wide load
+            const int t = u >> 2, pr = (u & 3) * 16 + (lane >> 2), chunk = lane & 3;
+            const int jn = pr >> 4, i = pr & 15;
+            const int ch = (i >> 2) * 16 + jn * 4 + (i & 3);
+            const int row = t * 64 + pr;
+            const int voff = ((ch * 9 + t) * 32 + ((chunk ^ sd_swz(row)) * 8)) * 2;
+            buffer_load16_lds(rs, lds_w + __builtin_amdgcn_readfirstlane(u * 1024), voff, 0);
+        }
+    }
+
+    // ---- 2. c0 rows 2ho-1, 2ho, 2ho+1 -> LDS (MFMA stem: stem_mfma_kernel's arithmetic, stem_common.h's K layout)
+    {
+        const u32x4 wf0 = p.stem_frag[lane], wf1 = p.stem_frag[64 + lane];
+        float sc[8], sh[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { sc[c] = p.s0_scale[g * 8 + c]; sh[c] = p.s0_shift[g * 8 + c]; }
+        const int tiles_per_row = S >> 4;
+        const int ntiles = 3 * tiles_per_row;
+        const float* const img_n = p.img + (int64_t)n * S * S * 3;
+        // this lane's share of a pixel's patch, relative to the tile's first pixel (stem_common.h): groups 0..2 read
+        // floats 0..7 of row y+g-1's run, group 3 float 8 of the three runs
+        const int lane_off = g < 3 ? ((g - 1) * S + q - 1) * 3 : (-S + q + 1) * 3 + 2;
+        for (int t0 = wave; t0 < ntiles; t0 += SD_WAVES * SD_UNROLL) {
+            float v[SD_UNROLL][8];
+            int xs[SD_UNROLL], rys[SD_UNROLL];          // rys: c0 row 0..2 | 4 if that row is outside the image
+            int ys[SD_UNROLL], xts[SD_UNROLL];
+            bool fast = true;                           // no tile of the batch is within 2 rows of the top / bottom border
+#pragma unroll
+            for (int u = 0; u < SD_UNROLL; ++u) {
+                // wave-uniform (scalar registers).  Past the end: redo the last tile (same values to the same slots)
+                const int tile = min(t0 + u * SD_WAVES, ntiles - 1);
+                const int ry = (tile >= tiles_per_row) + (tile >= 2 * tiles_per_row);
+                const int xt = tile - ry * tiles_per_row, y = 2 * ho - 1 + ry;
+                xs[u] = xt * 16 + q; ys[u] = y; xts[u] = xt;
+                rys[u] = (unsigned)y < (unsigned)S ? ry : ry | 4;
+                fast = fast && y >= 2 && y <= S - 3;      // rows y-1..y+1 inside, and the runs' overhang stays inside the image
+            }
+            // c0 value of (tile pixel, 8 channels) -> its slot of the strip.  column x: plane = x & 1; even plane slot
+            // x/2, odd plane slot (x+1)/2 (slot 0 = column -1)
+            auto strip_store = [&](int ry, int x, const u32x4& packed) {
+                const int plane = x & 1, row = (ry * 2 + plane) * PW + ((x + plane) >> 1);
+                *(u32x4*)(lds_s + row * 64 + ((g ^ sd_swz(row)) * 16)) = packed;
+            };
+            auto bn_act_pack = [&](const f32x4& a0, const f32x4& a1) {
+                float o[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[r] = apply_act_t<true, Y4_ACT_LEAKY>(fmaf(a0[r], sc[r], sh[r]));
+                    o[4 + r] = apply_act_t<true, Y4_ACT_LEAKY>(fmaf(a1[r], sc[4 + r], sh[4 + r]));
+                }
+                u32x4 packed;
+                E::store_chunk(&packed, o);
+                return packed;
+            };
+            if (fast) {
+                // branch-free batch: all loads back to back (one divergent if/else around them), then all MFMAs, then
+                // the epilogues, so that neither the load nor the MFMA latency is paid per tile
+                if (g < 3) {
+#pragma unroll
+                    for (int u = 0; u < SD_UNROLL; ++u) {
+                        const float* pp = img_n + (lane_off + (ys[u] * S + xts[u] * 16) * 3);
+                        f32x4 a, b;
+                        __builtin_memcpy(&a, pp, 16);
+                        __builtin_memcpy(&b, pp + 4, 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[u][e] = a[e]; v[u][4 + e] = b[e]; }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < SD_UNROLL; ++u) {
+                        const float* pp = img_n + (lane_off + (ys[u] * S + xts[u] * 16) * 3);
+                        v[u][0] = pp[0]; v[u][1] = pp[S * 3]; v[u][2] = pp[2 * S * 3];
+#pragma unroll
+                        for (int e = 3; e < 8; ++e) v[u][e] = 0.f;
+                    }
+                }
+                // left / right image border: the run's pixel x-1 (floats 0..2) or x+1 (floats 6, 7 and group 3's values)
+                // was read from the neighbouring row -- it is the conv's zero padding
+#pragma unroll
+                for (int u = 0; u < SD_UNROLL; ++u) {
+                    if (xts[u] != 0 && xts[u] != tiles_per_row - 1) continue;        // wave-uniform
+                    const bool lo = g < 3 ? xs[u] == 0 : xs[u] == S - 1, hi = xs[u] == S - 1;
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) v[u][e] = lo ? 0.f : v[u][e];
+                    v[u][6] = hi ? 0.f : v[u][6];
+                    v[u][7] = hi ? 0.f : v[u][7];
+                }
+                f32x4 a0[SD_UNROLL], a1[SD_UNROLL];
+#pragma unroll
+                for (int u = 0; u < SD_UNROLL; ++u) {
+                    u32x4 xf;
+                    E::store_chunk(&xf, v[u]);
+                    a0[u] = a1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    Mma<DT>::run(a0[u], wf0, xf);
+                    Mma<DT>::run(a1[u], wf1, xf);
+                }
+#pragma unroll
+                for (int u = 0; u < SD_UNROLL; ++u) {
+                    strip_store(rys[u], xs[u], bn_act_pack(a0[u], a1[u]));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < SD_UNROLL; ++u) {
+                    u32x4 packed = u32x4{0u, 0u, 0u, 0u};     // c0 rows outside the image are the conv's zero padding
+                    if (!(rys[u] & 4)) {
+                        stem_gather<true>(img_n, ys[u], xs[u], S, S, g, v[u]);
+                        u32x4 xf;
+                        E::store_chunk(&xf, v[u]);
+                        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                        Mma<DT>::run(a0, wf0, xf);
+                        Mma<DT>::run(a1, wf1, xf);
+                        packed = bn_act_pack(a0, a1);
+                    }
+                    strip_store(rys[u] & 3, xs[u], packed);
+                }
+            }
+        }
+        if (tid < 3 * 4) {                                    // the zero column left of the image
+            const int row = ((tid >> 2) * 2 + 1) * PW;
+            *(u32x4*)(lds_s + row * 64 + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- 3. stride-2 3x3 conv out of LDS.  Wave (wm, wn): pixel fragments wm, wm+8, ... x channel fragments
+    //         2wn, 2wn+1; taps outer so that a tap's weight fragments are read once per wave.
+    const int wm = wave % SD_WM, wn = wave / SD_WM;
+    f32x4 acc[MFW][2];
+#pragma unroll
+    for (int f = 0; f < MFW; ++f) acc[f][0] = acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ky = t / 3, kx = t - ky * 3;
+        u32x4 wf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = t * 64 + (wn * 2 + j) * 16 + q;
+            wf[j] = *(const u32x4*)(lds_w + row * 64 + ((g ^ sd_swz(row)) * 16));
+        }
+        // input column 2wo + kx - 1: kx = 0 -> odd plane slot wo, kx = 1 -> even plane slot wo, kx = 2 -> odd plane slot wo+1
+        const int row0 = (ky * 2 + (kx == 1 ? 0 : 1)) * PW + (kx == 2 ? 1 : 0) + q;
+#pragma unroll
+        for (int f = 0; f < MFW; ++f) {
+            const int frag = wm + SD_WM * f;
+            if (frag < MF) {                                  // wave-uniform
+                const int row = row0 + frag * 16;
+                const u32x4 xf = *(const u32x4*)(lds_s + row * 64 + ((g ^ sd_swz(row)) * 16));
+                Mma<DT>::run(acc[f][0], wf[0], xf);
+                Mma<DT>::run(acc[f][1], wf[1], xf);
+            }
+        }
+    }
+
+    // ---- 4. BN + activation; the lane holds channels g*16 + wn*8 + (0..7) of its pixel -> one 16-byte store
+    float sc[8], sh[8];
+#pragma unroll
+    for (int c = 0; c < 8; c += 4) {
+        const f32x4 s4 = *(const f32x4*)(p.s1_scale + g * 16 + wn * 8 + c);
+        const f32x4 h4 = *(const f32x4*)(p.s1_shift + g * 16 + wn * 8 + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[c + e] = s4[e]; sh[c + e] = h4[e]; }
+    }
+    T* const orow = (T*)p.out + ((int64_t)(n * Wo + ho) * Wo) * p.out_cstride + p.out_coff + g * 16 + wn * 8;
+#pragma unroll
+    for (int f = 0; f < MFW; ++f) {
+        const int frag = wm + SD_WM * f;
+        if (frag < MF) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[j * 4 + r] = apply_act_t<true, Y4_ACT_LEAKY>(fmaf(acc[f][j][r], sc[j * 4 + r], sh[j * 4 + r]));
+            u32x4 pk;
+            E::store_chunk(&pk, v);
+            *(u32x4*)(orow + (int64_t)(frag * 16 + q) * p.out_cstride) = pk;
+        }
+    }
+}
+
+size_t stem_down_lds_bytes(int S) { return (size_t)9 * 64 * 64 + (size_t)3 * 2 * (S / 2 + 1) * 64; }
+
+bool stem_down_supported(int dtype, int S) {
+    return dtype != Y4_F32 && S % 32 == 0 && stem_down_lds_bytes(S) <= 160 * 1024 && (S / 32 + SD_WM - 1) / SD_WM <= 3;
+}
+
+template <int DT>
+static int stem_down_dispatch(const StemDownK& k, hipStream_t stream) {
+    const int mfw = (k.S / 32 + SD_WM - 1) / SD_WM;         // ceil((Wo/16) / SD_WM)
+    const size_t lds = stem_down_lds_bytes(k.S);
+    const int blocks = k.N * (k.S / 2);
+#define Y4_SD_CASE(M)                                                                                        \
+    case M: {                                                                                                \
+        static bool attr_set = false;                                                                        \
+        if (!attr_set) {                                                                                     \
+            Y4_CHECK_HIP(hipFuncSetAttribute((const void*)stem_down_kernel<DT, M>,                          \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));       \
+            attr_set = true;                                                                                 \
+        }                                                                                                    \
+        hipLaunchKernelGGL((stem_down_kernel<DT, M>), dim3(blocks), dim3(64 * SD_WAVES), lds, stream, k);              \
+        break;                                                                                               \
+    }
+    switch (mfw) {
+        Y4_SD_CASE(1) Y4_SD_CASE(2) Y4_SD_CASE(3)
+        default: set_error("stem_down: image side %d not supported", k.S); return Y4_EINVAL;
+    }
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+int stem_down_launch(int dtype, const float* imgs, int n, int S, const void* stem_wk, const float* s0_scale,
+                     const float* s0_shift, int act0, const void* w1_packed, const float* s1_scale, const float* s1_shift,
+                     int act1, void* out, int out_cstride, int out_coff, hipStream_t stream) {
+    Y4_REQUIRE(stem_down_supported(dtype, S), Y4_EINVAL, "stem_down: dtype %d / image side %d not supported", dtype, S);
+    Y4_REQUIRE(imgs && stem_wk && w1_packed && out, Y4_EINVAL, "stem_down: null pointer");
+    Y4_REQUIRE(act0 == Y4_ACT_LEAKY && act1 == Y4_ACT_LEAKY, Y4_EINVAL, "stem_down: both convs are LeakyReLU in the plan (got %d, %d)", act0, act1);
+    Y4_REQUIRE((int64_t)n * S * S * 3 < (1ll << 31), Y4_EINVAL, "stem_down: image batch too large");
+    Y4_REQUIRE(out_cstride % 8 == 0 && out_coff % 8 == 0, Y4_EINVAL, "stem_down: output view not 16-byte aligned");
+    StemDownK k{};
+    k.img = imgs;
+    k.stem_frag = (const u32x4*)((const char*)stem_wk + (dtype == Y4_BF16 ? 4096 : 6144));
+    k.s0_scale = s0_scale; k.s0_shift = s0_shift; k.act0 = act0;
+    k.w1 = (const char*)w1_packed; k.s1_scale = s1_scale; k.s1_shift = s1_shift; k.act1 = act1;
+    k.w1_bytes = (unsigned)(round_up(64, COUT_PAD) * 9 * 32 * 2);
+    k.out = (char*)out; k.out_cstride = out_cstride; k.out_coff = out_coff;
+    k.N = n; k.S = S;
+    return dtype == Y4_BF16 ? stem_down_dispatch<Y4_BF16>(k, stream) : stem_down_dispatch<Y4_F16>(k, stream);
+}
+
+}  // namespace y4

@@ -272,6 +272,12 @@ class Engine:
         activations); 0 turns it off.  Results are unchanged."""
         ext.check(self.lib.y4_set_subbatch(self.handle, int(images), int(last_conv)))
 
+    def set_stem_fusion(self, on=True):
+        """Convs 0+1 as one kernel with conv 0's output kept in LDS (16-bit dtypes, img_size <= 640).  Results are
+        unchanged; conv_output(0) is unavailable while on."""
+        ext.check(self.lib.y4_set_stem_fusion(self.handle, int(bool(on))))
+        self.stem_fusion = bool(on)
+
     def timing_begin(self, max_steps, coarse=False):
         ext.check(self.lib.y4_timing_begin(self.handle, int(max_steps), int(bool(coarse))))
 
