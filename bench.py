@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--subbatch", type=int, default=0, help="images per sub-batch for the early layers (0 = whole batch)")
     ap.add_argument("--sub-last-conv", type=int, default=16)
     ap.add_argument("--no-stem-fusion", action="store_true", help="run convs 0 and 1 as two kernels (c0 through HBM)")
+    ap.add_argument("--no-chain-fusion", action="store_true", help="run the 3x3+Add -> 1x1 -> 1x1 runs as separate kernels")
     ap.add_argument("--per-op", action="store_true", help="also print the per-op time table to stderr")
     args = ap.parse_args()
 
@@ -101,6 +102,9 @@ def main():
     if fused_stem:
         eng.set_stem_fusion(True)          # convs 0+1 in one kernel; conv 1 then leaves the conv_igemm family below
     first_conv = 2 if fused_stem else 1
+    chained = 0
+    if args.dtype != "f32" and not args.no_chain_fusion:
+        chained = eng.set_chain_fusion(True)      # 3 runs (convs 5-6-7, 12-13, 14-15-16) -> one conv_igemm launch each
     if args.load_tiles:
         tiles = json.load(open(args.load_tiles))["tiles"]
         eng.set_tiles(tiles)
@@ -151,7 +155,7 @@ def main():
                        "sharding": f"batch split over {world} rank(s), no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
-                         "kernel": "conv_igemm_kernel (convs %d..109, %d launches/step)" % (first_conv, launches - (first_conv - 1)),
+                         "kernel": "conv_igemm_kernel (convs %d..109, %d launches/step)" % (first_conv, launches - (first_conv - 1) - (5 if chained else 0)),
                          "flops_per_step": conv_flops, "kernel_ms_per_step": round(conv_ms, 4),
                          "timed_steps": nrec},
             "breakdown_ms_per_step": {"conv_igemm": round(conv_ms, 4), ("stem_c0+c1_fused" if fused_stem else "stem_c0"): round(other.get("c0", 0.0), 4),

@@ -145,6 +145,17 @@ int y4_set_subbatch(y4_handle h, int images, int last_conv);
  * profile reports the pair under 'c0' ('c1' reads 0).  Y4_EINVAL if the dtype / size is not supported. */
 int y4_set_stem_fusion(y4_handle h, int on);
 
+/* Scheduling knob (16-bit dtypes): run each "3x3 conv + residual Add -> 1x1 conv [-> 1x1 conv over
+ * Concatenate([., route])]" run of the CSP stages with 64-channel blocks (reference custom_layers.py:41-44, :66-69
+ * and the conv that follows csp_block, :104/:109) as ONE kernel: the intermediate tensors stay in registers instead
+ * of going through HBM.  Same products, fp32-accumulated in a different order: results agree with the unfused path
+ * to 16-bit rounding, not bitwise.  Returns the number of fused runs (>= 0) when turned on, Y4_OK when turned off,
+ * a negative Y4_E* code on error.  While on, y4_get_conv_output of a conv inside a run (not its last) reads a
+ * tensor that is not materialised.  y4_autotune then also decides per run, by measurement, whether it executes as
+ * one kernel or as separate ones; y4_get_tiles reports a fused run's head conv as MINUS its tile id (y4_set_tiles
+ * accepts the same encoding; > 0 there means separate kernels, 0 fused with the built-in tile). */
+int y4_set_chain_fusion(y4_handle h, int on);
+
 /* Live per-op timing of the calls in between: while a session is open, each y4_predict (up to max_steps of
  * them) records a HIP event on its stream after every op, without synchronising.  y4_timing_end
  * synchronises the stream and returns the mean device time per op in ms ('c1'.., 'spp', 'decode', 'nms').

@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wn
 mkdir -p build
 pids=()
 for f in conv_igemm misc_kernels stem_down decode_nms runtime; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ conv_common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ ../../include/yolo4hip.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ conv_common.h -nt build/$f.o ] || [ conv_chain.h -nt build/$f.o ] || [ stem_common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ ../../include/yolo4hip.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi

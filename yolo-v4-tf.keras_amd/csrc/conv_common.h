@@ -11,6 +11,16 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
+// A 1x1 conv chained onto the producing conv's register tile (conv_chain.h)
+struct ChainTail {
+    const char* w;                 // fragment-ordered weights (pack_tail_weights)
+    const float* scale;
+    const float* shift;
+    const char* src2;              // second 64-channel input slice (the concat partner), or null
+    int src2_cstride, src2_coff;
+    int cout;                      // 64 or 128
+};
+
 struct ConvK {
     const char* in;
     const char* wt;
@@ -28,6 +38,12 @@ struct ConvK {
     FastDiv div_gridn;
     char* out2;                    // channels >= split go to this view (fused CSP route + main-in pair)
     int out2_cstride, out2_coff, split;
+    // chained 1x1 convs (ntail > 0): `out` is this conv's own output view, written only if store_x; the last
+    // tail writes `fin`
+    int ntail, store_x;
+    ChainTail tail[2];
+    char* fin;
+    int fin_cstride, fin_coff;
 };
 
 template <int CPR> __device__ __forceinline__ int swz(int row) {

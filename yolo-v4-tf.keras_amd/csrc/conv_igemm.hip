@@ -16,12 +16,12 @@
 // ds_read_b128 lane group hits 16 distinct slots; global_load_lds writes LDS lane-linearly, so the
 // swizzle is applied to the per-lane SOURCE address and again on the fragment read (same involution).
 // Pipeline: 2 LDS stages, one barrier per K-tile: loads of tile t+1 fly during the MFMAs of tile t.
-#include "conv_common.h"
+#include "conv_chain.h"
 
 namespace y4 {
 
-template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p) {
+template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0>
+__global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel(const ConvK p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int ES = (DT == Y4_F32) ? 4 : 2;
     constexpr int BK = BKB / ES;            // K elements per tile
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
+    if constexpr (CHAIN != 0) chain_stage_weights<CHAIN, WM * WN>(p, smem + SN * STAGE, __builtin_amdgcn_readfirstlane(wave), lane);
 
     // ---- staging set-up: this thread copies physical chunk slot `q` of rows r0 + j*RPI.
     // Loads are buffer_load_dwordx4 ... lds through two raw buffer descriptors (activations, weights): the
@@ -260,9 +261,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
     }
 
     // ---- epilogue (conv_common.h): scale/shift, activation, residual, packed converts, slice / upsampled / split store
-    const int chb = n0 + wn * WCH + fg * CPL;       // this lane's first channel
-    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.cout_store);
-    conv_epilogue<DT, MREP, NREP>(p, acc, m0 + wm * WPX + frow, p.M, chb, full);
+    if constexpr (CHAIN) {
+        // chained 1x1 convs consume the tile straight from the accumulators (conv_chain.h)
+        static_assert(WN == 1 && BN == 64 && DT != Y4_F32, "chain head: one wave column over all 64 channels, 16-bit");
+        chain_epilogue<DT, MREP, CHAIN>(p, smem + SN * STAGE, acc, m0 + wm * WPX + frow, p.M, lane);
+    } else {
+        const int chb = n0 + wn * WCH + fg * CPL;       // this lane's first channel
+        const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.cout_store);
+        conv_epilogue<DT, MREP, NREP>(p, acc, m0 + wm * WPX + frow, p.M, chb, full);
+    }
 }
 
 // ------------------------------------------------------------------------------------------- launch
@@ -311,10 +318,10 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 int conv_tile_count() { return kNumTiles; }
 
-template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST>
+template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0>
 static int launch_cfg(const ConvK& k, hipStream_t stream) {
-    constexpr int lds = (NST == 12 ? 2 : NST) * (BM + BN) * BKB;
-    auto kern = conv_igemm_kernel<DT, BM, BN, WM, WN, BKB, NST>;
+    constexpr int lds = (NST == 12 ? 2 : NST) * (BM + BN) * BKB + (CHAIN ? ChainLds<CHAIN ? CHAIN : 1>::BYTES : 0);
+    auto kern = conv_igemm_kernel<DT, BM, BN, WM, WN, BKB, NST, CHAIN>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         Y4_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -327,8 +334,28 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
 
 constexpr int F32_TILES = 12;
 
+// chain heads: the tiles with one wave column over 64 channels
+static bool chain_tile(int tile) { return tile == 3 || tile == 4 || tile == 15; }
+
 template <int DT>
 static int launch_dt(int tile, const ConvK& k, hipStream_t s) {
+    if (k.ntail > 0) {
+        if constexpr (DT != Y4_F32) {
+            const int cfg = k.ntail == 1 ? 1 : (k.tail[1].cout == 64 ? 2 : 3);
+#define Y4_CHAIN_CASE(CFG)                                                                   \
+    case CFG:                                                                                \
+        switch (tile) {                                                                      \
+            case 3: return launch_cfg<DT, 128, 64, 4, 1, 128, 2, CFG>(k, s);                 \
+            case 4: return launch_cfg<DT, 128, 64, 4, 1, 64, 2, CFG>(k, s);                  \
+            case 15: return launch_cfg<DT, 128, 64, 4, 1, 64, 4, CFG>(k, s);                 \
+        }                                                                                    \
+        break;
+            switch (cfg) { Y4_CHAIN_CASE(1) Y4_CHAIN_CASE(2) Y4_CHAIN_CASE(3) }
+#undef Y4_CHAIN_CASE
+        }
+        set_error("conv2d: tile id %d cannot head a chain", tile);
+        return Y4_EINVAL;
+    }
     // the fp32 (parity) path instantiates only the first F32_TILES configurations (build time)
 #define Y4_TILE_CASE(id, bm, bn, wm, wn, bkb, nst)                                            \
     case id:                                                                                  \
@@ -354,7 +381,7 @@ int conv_pick_tile(int dtype, int M, int cin, int cout) {
     return k128 ? 8 : 9;      // 64x128: more, smaller blocks overlap load / MFMA / store phases best (measured)
 }
 
-int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream) {
+int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream, const ConvChainDesc* chain) {
     Y4_REQUIRE(d && d->in && d->wt && d->out && d->scale && d->shift, Y4_EINVAL, "conv2d: null pointer");
     Y4_REQUIRE(d->dtype >= Y4_F32 && d->dtype <= Y4_F16, Y4_EINVAL, "conv2d: bad dtype %d", d->dtype);
     Y4_REQUIRE(d->ksize == 1 || d->ksize == 3, Y4_EINVAL, "conv2d: ksize %d (only 1 or 3)", d->ksize);
@@ -393,7 +420,24 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
     k.ksize = d->ksize; k.stride = d->stride; k.pad = d->ksize == 3 ? 1 : 0;
     k.act = d->act; k.upsample = d->upsample; k.out_f32 = d->out_f32;
     const int cout_pad = (int)round_up(d->cout, COUT_PAD);
-    int tile = d->tile ? d->tile : conv_pick_tile(d->dtype, k.M, d->cin, d->cout);
+    if (chain && chain->ntail > 0) {
+        Y4_REQUIRE(d->dtype != Y4_F32 && d->cout == 64 && d->act == Y4_ACT_MISH && !d->upsample && !d->out_f32 && !d->out2 &&
+                       chain->ntail <= 2 && chain->fin && chain->fin_cstride % epc == 0 && chain->fin_coff % epc == 0,
+                   Y4_EINVAL, "conv2d: bad chain description");
+        k.ntail = chain->ntail; k.store_x = chain->store_x;
+        k.fin = (char*)chain->fin; k.fin_cstride = chain->fin_cstride; k.fin_coff = chain->fin_coff;
+        for (int t = 0; t < chain->ntail; ++t) {
+            const auto& ct = chain->tail[t];
+            Y4_REQUIRE(ct.w && ct.scale && ct.shift && (ct.cout == 64 || (ct.cout == 128 && t == chain->ntail - 1)) &&
+                           ((t == 1) == (ct.src2 != nullptr)) && (!ct.src2 || (ct.src2_cstride % epc == 0 && ct.src2_coff % epc == 0)),
+                       Y4_EINVAL, "conv2d: bad chain tail %d", t);
+            k.tail[t].w = (const char*)ct.w; k.tail[t].scale = ct.scale; k.tail[t].shift = ct.shift;
+            k.tail[t].src2 = (const char*)ct.src2; k.tail[t].src2_cstride = ct.src2_cstride; k.tail[t].src2_coff = ct.src2_coff;
+            k.tail[t].cout = ct.cout;
+        }
+    }
+    int tile = d->tile ? d->tile : (k.ntail > 0 ? (d->cin % (128 / es) == 0 ? 3 : 4) : conv_pick_tile(d->dtype, k.M, d->cin, d->cout));
+    Y4_REQUIRE(k.ntail == 0 || chain_tile(tile), Y4_EINVAL, "conv2d: tile id %d cannot head a chain", tile);
     Y4_REQUIRE(tile >= 1 && tile <= kNumTiles, Y4_EINVAL, "conv2d: tile id %d out of range", tile);
     const TileCfg& tc = kTiles[tile - 1];
     Y4_REQUIRE(tile_ok(tc, d->dtype, d->cin, cout_pad), Y4_EINVAL,
@@ -437,6 +481,37 @@ int pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw
         case Y4_BF16: hipLaunchKernelGGL(pack_conv_kernel<Y4_BF16>, dim3(blocks), dim3(256), 0, stream, oihw, (uint16_t*)packed, cout, cout_pad, cin, kk); break;
         case Y4_F16: hipLaunchKernelGGL(pack_conv_kernel<Y4_F16>, dim3(blocks), dim3(256), 0, stream, oihw, (_Float16*)packed, cout, cout_pad, cin, kk); break;
         default: set_error("pack_conv_weights: bad dtype %d", dtype); return Y4_EINVAL;
+    }
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+// 1x1 conv weights (cout, cin, 1, 1) -> MFMA A fragments in the chain's K order (conv_chain.h):
+// out[((src*2 + s)*NREP2 + j2)*64 + lane][e] = W[ch2][src*64 + 16*(lane>>4) + 8*s + e],
+// ch2 = (i>>2)*CPL2 + j2*4 + (i&3), i = lane & 15, NREP2 = cout/16, CPL2 = cout/4.
+template <int DT>
+__global__ void pack_tail_kernel(const float* __restrict__ w, typename Elem<DT>::type* __restrict__ out, int cout, int cin) {
+    const int total = cout * cin, nrep2 = cout / 16, cpl2 = cout / 4;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 7, lane = (idx >> 3) & 63;
+        int r = idx >> 9;
+        const int j2 = r % nrep2; r /= nrep2;
+        const int s = r & 1, src = r >> 1;
+        const int i = lane & 15, g = lane >> 4;
+        const int ch2 = (i >> 2) * cpl2 + j2 * 4 + (i & 3);
+        const int ci = src * 64 + 16 * g + 8 * s + e;
+        out[idx] = Elem<DT>::st(w[ch2 * cin + ci]);
+    }
+}
+
+int pack_tail_weights(int dtype, int cout, int cin, const float* oihw, void* packed, hipStream_t stream) {
+    Y4_REQUIRE((cout == 64 || cout == 128) && (cin == 64 || cin == 128) && oihw && packed, Y4_EINVAL,
+               "pack_tail_weights: cout %d cin %d", cout, cin);
+    const int blocks = (cout * cin + 255) / 256;
+    switch (dtype) {
+        case Y4_BF16: hipLaunchKernelGGL(pack_tail_kernel<Y4_BF16>, dim3(blocks), dim3(256), 0, stream, oihw, (uint16_t*)packed, cout, cin); break;
+        case Y4_F16: hipLaunchKernelGGL(pack_tail_kernel<Y4_F16>, dim3(blocks), dim3(256), 0, stream, oihw, (_Float16*)packed, cout, cin); break;
+        default: set_error("pack_tail_weights: 16-bit dtypes only (got %d)", dtype); return Y4_EINVAL;
     }
     Y4_CHECK_HIP(hipGetLastError());
     return Y4_OK;

@@ -5,7 +5,22 @@
 namespace y4 {
 
 // conv_igemm.hip
-int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream);
+// 1x1 convs chained onto a conv's register tile (conv_chain.h); d->out is then the head conv's own output view,
+// written only if store_x, and the last tail writes `fin`.  16-bit dtypes, head cout == 64, Mish everywhere.
+struct ConvChainDesc {
+    int ntail, store_x;
+    struct {
+        const void* w;             // pack_tail_weights layout
+        const float* scale;
+        const float* shift;
+        const void* src2;          // concat partner slice (64 channels) or null
+        int src2_cstride, src2_coff, cout;
+    } tail[2];
+    void* fin;
+    int fin_cstride, fin_coff;
+};
+int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream, const ConvChainDesc* chain = nullptr);
+int pack_tail_weights(int dtype, int cout, int cin, const float* oihw, void* packed, hipStream_t stream);
 int conv_tile_count();
 int conv_pick_tile(int dtype, int M, int cin, int cout);
 int pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw, void* packed, hipStream_t stream);

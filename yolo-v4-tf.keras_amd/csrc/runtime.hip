@@ -53,6 +53,17 @@ struct Layer {
     int fused_row = 0;
     int extra_rows = 0;    // rows appended by a fused partner
     size_t w_off, scale_off, shift_off;   // byte offsets in the wts workspace
+    bool has_tail = false;                // a chain can run this 1x1 conv as a tail: its weights are also kept in
+    size_t tail_off = 0;                  // fragment order (pack_tail_weights) at this offset
+};
+
+// A run of ops executed as one kernel (conv_chain.h): head = 3x3 conv with residual Add and 64 output channels,
+// then one or two 1x1 convs; the second reads Concatenate([first tail's output, route]).
+struct Chain {
+    int head, tail[2];      // op indices (tail[1] = -1 for a 2-conv chain)
+    bool store_x;           // the head's output has other consumers and is still written
+    bool enabled = true;    // y4_autotune turns a run off when its separate kernels measure faster
+    int tile = 0;           // the head's tile when it runs chained (0 = heuristic); Op::tile stays the unfused choice
 };
 
 }  // namespace y4
@@ -89,6 +100,9 @@ struct y4_ctx {
     int sub_images = 0, sub_last_op = -1;
     // convs 0+1 as one kernel (stem_down.hip): op 0 launches it into op 1's output view, op 1 becomes a no-op
     bool fuse_stem = false;
+    // 3x3+Add -> 1x1 (-> 1x1 over the concat) runs found in the plan, executed as one kernel each when fuse_chains
+    std::vector<Chain> chains;
+    bool fuse_chains = false;
     bool t_recorded_this_call = false;
 };
 
@@ -235,6 +249,49 @@ struct Builder {
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+bool same_view(const View& a, const View& b) { return a.buf == b.buf && a.coff == b.coff && a.c == b.c; }
+
+// Find the 3x3+Add -> 1x1 [-> 1x1 over Concatenate([., route])] runs of the plan that conv_chain.h can execute as one
+// kernel (16-bit dtypes): head cout 64, Mish everywhere, tails 64 -> 64 and 128 -> 64|128.
+void find_chains(y4_ctx& c) {
+    if (c.cfg.dtype == Y4_F32) return;
+    const int nops = (int)c.ops.size();
+    auto readers = [&](int buf, int except_a, int except_b) {     // does any other op read this buffer?
+        for (int i = 0; i < nops; ++i) {
+            if (i == except_a || i == except_b) continue;
+            const Op& o = c.ops[i];
+            if (o.in.buf == buf || (o.has_res && o.res.buf == buf)) return true;
+        }
+        return false;
+    };
+    for (int i = 0; i + 1 < nops; ++i) {
+        const Op& a = c.ops[i];
+        const Op& b = c.ops[i + 1];
+        if (a.kind != OP_CONV || b.kind != OP_CONV || a.conv2 >= 0 || b.conv2 >= 0) continue;
+        const Layer& la = c.layers[a.conv];
+        const Layer& lb = c.layers[b.conv];
+        if (!(la.d.ksize == 3 && la.d.stride == 1 && a.has_res && la.d.cout == 64 && la.d.act == Y4_ACT_MISH && !a.upsample)) continue;
+        if (!(lb.d.ksize == 1 && lb.d.cin == 64 && lb.d.cout == 64 && lb.d.act == Y4_ACT_MISH && !b.has_res && !b.upsample &&
+              !b.out_f32 && same_view(b.in, a.out)))
+            continue;
+        Chain ch{i, {i + 1, -1}, readers(a.out.buf, i + 1, -1)};
+        if (i + 2 < nops) {
+            const Op& d = c.ops[i + 2];
+            if (d.kind == OP_CONV && d.conv2 < 0) {
+                const Layer& ld = c.layers[d.conv];
+                // d reads the whole concat buffer whose first 64 channels are b's output
+                if (ld.d.ksize == 1 && ld.d.cin == 128 && (ld.d.cout == 64 || ld.d.cout == 128) && ld.d.act == Y4_ACT_MISH &&
+                    !d.has_res && !d.upsample && !d.out_f32 && d.in.buf == b.out.buf && d.in.coff == 0 && b.out.coff == 0 &&
+                    d.in.cstride == 128 && !readers(b.out.buf, i + 2, -1))
+                    ch.tail[1] = i + 2;
+            }
+        }
+        c.layers[b.conv].has_tail = true;
+        if (ch.tail[1] >= 0) c.layers[c.ops[ch.tail[1]].conv].has_tail = true;
+        c.chains.push_back(ch);
+    }
+}
+
 void layout(y4_ctx& c) {
     // ---- activations
     size_t off = 0;
@@ -260,6 +317,7 @@ void layout(y4_ctx& c) {
         L.w_off = off; off = align256(off + wbytes);
         L.scale_off = off; off = align256(off + rows * 4);
         L.shift_off = off; off = align256(off + rows * 4);
+        if (L.has_tail) { L.tail_off = off; off = align256(off + (size_t)L.d.cout * L.d.cin * c.es); }
     }
     c.wts_bytes = off;
 }
@@ -297,7 +355,7 @@ void build_schedule(y4_handle h, int n, std::vector<Launch>& out) {
     for (int i = first_full; i < nops; ++i) out.push_back({i, 0, n});
 }
 
-int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s, int img0 = 0) {
+int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s, int img0 = 0, bool allow_chain = true) {
     if (op.kind == OP_SPP) return spp_launch(h->cfg.dtype, buf_ptr(h, op.in, img0), n, op.in.side, op.in.cstride / 4, s);
     const Layer& L = h->layers[op.conv];
     const float* scale = (const float*)(h->wts + L.scale_off);
@@ -311,6 +369,13 @@ int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s, i
                                 buf_ptr(h, o1.out, img0), o1.out.cstride, o1.out.coff, s);
     }
     if (h->fuse_stem && op.kind == OP_CONV && op.conv == 1) return Y4_OK;
+    const Chain* chain = nullptr;
+    if (h->fuse_chains && allow_chain && op.kind == OP_CONV)
+        for (const Chain& ch : h->chains) {
+            if (!ch.enabled) continue;
+            if (&h->ops[ch.head] == &op) chain = &ch;
+            else if (&h->ops[ch.tail[0]] == &op || (ch.tail[1] >= 0 && &h->ops[ch.tail[1]] == &op)) return Y4_OK;   // ran with its head
+        }
     if (op.kind == OP_STEM)
         return stem_conv_launch(h->cfg.dtype, imgs ? imgs + (size_t)img0 * h->S * h->S * 3 : imgs, n, h->S, h->S,
                                 (const float*)(h->wts + L.w_off), scale, shift, L.d.cout, L.d.act,
@@ -326,7 +391,29 @@ int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s, i
     d.out = buf_ptr(h, op.out, img0);
     if (op.has_res) { d.res = buf_ptr(h, op.res, img0); d.res_cstride = op.res.cstride; d.res_coff = op.res.coff; }
     if (op.conv2 >= 0) { d.out2 = buf_ptr(h, op.out2, img0); d.out2_cstride = op.out2.cstride; d.out2_coff = op.out2.coff; d.split = op.split; }
-    d.tile = op.tile;
+    d.tile = chain ? chain->tile : op.tile;
+    if (chain) {
+        ConvChainDesc cd{};
+        cd.store_x = chain->store_x ? 1 : 0;
+        const Op* last = &op;
+        for (int t = 0; t < 2 && chain->tail[t] >= 0; ++t) {
+            const Op& to = h->ops[chain->tail[t]];
+            const Layer& TL = h->layers[to.conv];
+            cd.tail[t].w = h->wts + TL.tail_off;
+            cd.tail[t].scale = (const float*)(h->wts + TL.scale_off);
+            cd.tail[t].shift = (const float*)(h->wts + TL.shift_off);
+            cd.tail[t].cout = TL.d.cout;
+            if (t == 1) {                       // the concat partner: channels [64, 128) of the buffer the first tail writes into
+                cd.tail[t].src2 = buf_ptr(h, to.in, img0);
+                cd.tail[t].src2_cstride = to.in.cstride;
+                cd.tail[t].src2_coff = to.in.coff + 64;
+            }
+            cd.ntail = t + 1;
+            last = &to;
+        }
+        cd.fin = buf_ptr(h, last->out, img0); cd.fin_cstride = last->out.cstride; cd.fin_coff = last->out.coff;
+        return conv2d_launch(&d, h->act + h->zero_off, s, &cd);
+    }
     return conv2d_launch(&d, h->act + h->zero_off, s);
 }
 
@@ -399,6 +486,7 @@ int y4_create(const y4_config* cfg, y4_handle* out) {
         return Y4_EINVAL;
     }
     Builder(*c).build();
+    find_chains(*c);
     layout(*c);
     *out = c;
     return Y4_OK;
@@ -469,6 +557,8 @@ int y4_pack_weights(y4_handle h, const float* blob, size_t n_floats, void* strea
             if (int r = pack_stem_weights(w, (float*)(h->wts + L.w_off), L.d.cout, s)) return r;
         } else {
             if (int r = pack_conv_weights(h->cfg.dtype, L.d.cout, L.d.cin, L.d.ksize, w, wdst, s)) return r;
+            if (L.has_tail)
+                if (int r = pack_tail_weights(h->cfg.dtype, L.d.cout, L.d.cin, w, h->wts + L.tail_off, s)) return r;
         }
     }
     h->weights_ready = true;
@@ -611,25 +701,51 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
     Y4_CHECK_HIP(hipEventCreate(&e1));
     int rc = Y4_OK;
     const int ntiles = conv_tile_count();
-    for (int oi = 0; oi < (int)h->ops.size(); ++oi) {
+    // time `reps` launches of one op; < 0: this tile does not fit, -2: HIP failure
+    auto time_op = [&](const Op& op, int ne, bool chained) -> float {
+        if (run_op(h, op, nullptr, ne, s, 0, chained) != Y4_OK) return -1.f;
+        if (hipEventRecord(e0, s) != hipSuccess) return -2.f;
+        for (int i = 0; i < reps; ++i) run_op(h, op, nullptr, ne, s, 0, chained);
+        float ms = 0.f;
+        if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+            hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+            return -2.f;
+        return ms;
+    };
+    auto images_of = [&](int oi) { return (h->sub_images > 0 && oi <= h->sub_last_op && n > h->sub_images) ? h->sub_images : n; };
+    // pass 1: every conv as its own kernel
+    std::vector<float> best_ms(h->ops.size(), 0.f);
+    for (int oi = 0; oi < (int)h->ops.size() && rc == Y4_OK; ++oi) {
         Op& op = h->ops[oi];
         if (op.kind != OP_CONV || (h->fuse_stem && op.conv == 1)) continue;
-        const int ne = (h->sub_images > 0 && oi <= h->sub_last_op && n > h->sub_images) ? h->sub_images : n;
         float best = 1e30f;
         int best_tile = 0;
-        for (int tile = 1; tile <= ntiles && rc == Y4_OK; ++tile) {
+        for (int tile = 1; tile <= ntiles; ++tile) {
             op.tile = tile;
-            if (run_op(h, op, nullptr, ne, s) != Y4_OK) continue;     // tile does not fit this shape
-            if (hipEventRecord(e0, s) != hipSuccess) { rc = Y4_EHIP; break; }
-            for (int i = 0; i < reps; ++i) run_op(h, op, nullptr, ne, s);
-            float ms = 0.f;
-            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
-                hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = Y4_EHIP; break; }
-            if (ms < best) { best = ms; best_tile = tile; }
+            const float ms = time_op(op, images_of(oi), false);
+            if (ms == -2.f) { rc = Y4_EHIP; break; }
+            if (ms >= 0.f && ms < best) { best = ms; best_tile = tile; }
         }
         op.tile = best_tile;
-        if (rc != Y4_OK) break;
+        best_ms[oi] = best;
     }
+    // pass 2: each chain as one kernel against the sum of its separate kernels
+    if (h->fuse_chains)
+        for (Chain& ch : h->chains) {
+            if (rc != Y4_OK) break;
+            float separate = best_ms[ch.head] + best_ms[ch.tail[0]] + (ch.tail[1] >= 0 ? best_ms[ch.tail[1]] : 0.f);
+            float best = 1e30f;
+            int best_tile = 0;
+            ch.enabled = true;
+            for (int tile = 1; tile <= ntiles; ++tile) {
+                ch.tile = tile;
+                const float ms = time_op(h->ops[ch.head], images_of(ch.head), true);
+                if (ms == -2.f) { rc = Y4_EHIP; break; }
+                if (ms >= 0.f && ms < best) { best = ms; best_tile = tile; }
+            }
+            ch.tile = best_tile;
+            ch.enabled = best_tile > 0 && best < separate;
+        }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc != Y4_OK) set_error("y4_autotune: HIP event failure");
@@ -639,11 +755,23 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
 int y4_set_tiles(y4_handle h, const int32_t* tiles, int count) {
     if (int r = check_handle(h)) return r;
     Y4_REQUIRE(tiles && count == (int)h->layers.size(), Y4_EINVAL, "y4_set_tiles: expected %d entries", (int)h->layers.size());
-    for (Op& op : h->ops)
-        if (op.kind == OP_CONV) {
-            Y4_REQUIRE(tiles[op.conv] >= 0 && tiles[op.conv] <= conv_tile_count(), Y4_EINVAL, "y4_set_tiles: tile id %d", tiles[op.conv]);
-            op.tile = tiles[op.conv];
+    for (int oi = 0; oi < (int)h->ops.size(); ++oi) {
+        Op& op = h->ops[oi];
+        if (op.kind != OP_CONV) continue;
+        const int v = tiles[op.conv];
+        Chain* head_of = nullptr;
+        for (Chain& ch : h->chains)
+            if (ch.head == oi) head_of = &ch;
+        Y4_REQUIRE(v <= conv_tile_count() && -v <= conv_tile_count() && (v >= 0 || (head_of && h->fuse_chains)), Y4_EINVAL,
+                   "y4_set_tiles: tile id %d for conv %d", v, op.conv);
+        if (head_of && h->fuse_chains) {      // < 0: chained with tile -v; > 0: separate kernels; 0: chained, heuristic tile
+            head_of->enabled = v <= 0;
+            head_of->tile = v < 0 ? -v : 0;
+            if (v > 0) op.tile = v;
+        } else {
+            op.tile = v;
         }
+    }
     return Y4_OK;
 }
 
@@ -675,6 +803,15 @@ int y4_set_stem_fusion(y4_handle h, int on) {
     return Y4_OK;
 }
 
+int y4_set_chain_fusion(y4_handle h, int on) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(h->t_max_steps == 0, Y4_ESTATE, "y4_set_chain_fusion: a timing session is open");
+    Y4_REQUIRE(!on || h->cfg.dtype != Y4_F32, Y4_EINVAL, "y4_set_chain_fusion: 16-bit dtypes only");
+    h->fuse_chains = on != 0;
+    for (Chain& ch : h->chains) { ch.enabled = true; ch.tile = 0; }
+    return on ? (int)h->chains.size() : Y4_OK;
+}
+
 int y4_get_tiles(y4_handle h, int32_t* tiles, int cap) {
     if (int r = check_handle(h)) return r;
     Y4_REQUIRE(tiles && cap >= (int)h->layers.size(), Y4_EINVAL, "y4_get_tiles: need room for %d layers", (int)h->layers.size());
@@ -684,6 +821,9 @@ int y4_get_tiles(y4_handle h, int32_t* tiles, int cap) {
             tiles[op.conv] = op.tile;
             if (op.conv2 >= 0) tiles[op.conv2] = op.tile;
         }
+    if (h->fuse_chains)                       // a chained run reports its head as -tile (see y4_set_tiles)
+        for (const Chain& ch : h->chains)
+            if (ch.enabled) tiles[h->ops[ch.head].conv] = -ch.tile;
     return Y4_OK;
 }
 

@@ -278,6 +278,15 @@ class Engine:
         ext.check(self.lib.y4_set_stem_fusion(self.handle, int(bool(on))))
         self.stem_fusion = bool(on)
 
+    def set_chain_fusion(self, on=True):
+        """3x3+Add -> 1x1 (-> 1x1 over the concat) runs of the 64-channel CSP stages as one kernel each (16-bit
+        dtypes).  Returns the number of fused runs.  Equal to the unfused path up to 16-bit rounding, not bitwise."""
+        r = self.lib.y4_set_chain_fusion(self.handle, int(bool(on)))
+        if r < 0:
+            ext.check(r)
+        self.chain_fusion = bool(on)
+        return r
+
     def timing_begin(self, max_steps, coarse=False):
         ext.check(self.lib.y4_timing_begin(self.handle, int(max_steps), int(bool(coarse))))
 
