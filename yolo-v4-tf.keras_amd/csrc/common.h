@@ -100,10 +100,13 @@ template <> struct Elem<Y4_F16> {
 // beyond its threshold).
 template <bool FAST>
 __device__ __forceinline__ float mish_f(float x) {
-    if (FAST) {   // 16-bit storage paths: v_exp_f32 + v_rcp_f32 (~1 ulp each), far below bf16/fp16 resolution
-        const float e = __builtin_amdgcn_exp2f(fminf(x, 20.f) * 1.4426950408889634f);
-        const float n = e * (e + 2.f);
-        return x * (n * __builtin_amdgcn_rcpf(n + 2.f));          // x > 20: n/(n+2) rounds to 1 anyway
+    if (FAST) {
+        // 16-bit storage paths: tanh(softplus(x)) = 1 - 2/(e*e + 2e + 2) in 7 VALU ops (v_exp_f32 + v_rcp_f32, ~1 ulp
+        // each).  No clamp: e = inf gives rcp = 0 and the factor 1.  The subtraction cancels only for x << 0, where
+        // the absolute error |x| * 1.5e-7 stays below the storage type's resolution (|mish(x)| < 3e-3 for x < -8).
+        const float e = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+        const float r = __builtin_amdgcn_rcpf(fmaf(e, e + 2.f, 2.f));
+        return x * fmaf(-2.f, r, 1.f);
     }
     const float e = expf(fminf(x, 20.f));
     const float n = e * (e + 2.f);

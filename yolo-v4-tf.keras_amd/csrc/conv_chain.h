@@ -114,45 +114,59 @@ __device__ __forceinline__ void chain_stage_weights(const ConvK& p, char* lds, i
     }
 }
 
+// The chain's HBM inputs besides the head conv's own operands: the residual and the concat partner.  They depend on
+// nothing, so the kernel issues these loads BEFORE the head's K loop (32 VGPRs held across it) and their round trip
+// is hidden under it instead of being paid at the epilogue.  Both are this lane's 16 channels of its pixels.
+template <int MREP> struct ChainPrefetch {
+    u32x4 res[MREP][2], x2[MREP][2];
+};
+template <int DT, int MREP, int CFG>
+__device__ __forceinline__ void chain_prefetch(const ConvK& p, ChainPrefetch<MREP>& pf, int mrow, int m_limit, int lane) {
+    using T = typename Elem<DT>::type;
+    const int chb = (lane >> 4) * 16;
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = mrow + i * 16;
+        const int64_t mm = m < m_limit ? m : 0;
+        if (p.res) {
+            const T* rp = (const T*)p.res + mm * p.res_cstride + p.res_coff + chb;
+            pf.res[i][0] = *(const u32x4*)rp;
+            pf.res[i][1] = *(const u32x4*)(rp + 8);
+        }
+        if constexpr (CFG != 1) {
+            const ChainTail& t1 = p.tail[1];
+            const T* sp = (const T*)t1.src2 + mm * t1.src2_cstride + t1.src2_coff + chb;
+            pf.x2[i][0] = *(const u32x4*)sp;
+            pf.x2[i][1] = *(const u32x4*)(sp + 8);
+        }
+    }
+}
+
 // Epilogue of a chain head (NREP == 4, one wave column): BN + Mish (+ residual) into fragment registers, then the tails.
 template <int DT, int MREP, int CFG>
-__device__ __forceinline__ void chain_epilogue(const ConvK& p, const char* lds_w, f32x4 (&acc)[MREP][4], int mrow, int m_limit,
-                                               int lane) {
+__device__ __forceinline__ void chain_epilogue(const ConvK& p, const char* lds_w, f32x4 (&acc)[MREP][4],
+                                               const ChainPrefetch<MREP>& pf, int mrow, int m_limit, int lane) {
     using E = Elem<DT>;
     using T = typename E::type;
     const int fg = lane >> 4, chb = fg * 16;
     float sc[16], sh[16];
     chain_load_affine<16>(p.scale, p.shift, chb, sc, sh);
-    u32x4 X[MREP][2], X2[MREP][2];
-    if constexpr (CFG != 1) {
-        // the last tail's second input (the concat partner): this lane's 16 channels of its pixels are already in
-        // fragment order in HBM; loaded first so that the round trip overlaps everything up to that tail
-        const ChainTail& t1 = p.tail[1];
-#pragma unroll
-        for (int i = 0; i < MREP; ++i) {
-            const int m = mrow + i * 16;
-            const T* sp = (const T*)t1.src2 + (int64_t)(m < m_limit ? m : 0) * t1.src2_cstride + t1.src2_coff + chb;
-            X2[i][0] = *(const u32x4*)sp;
-            X2[i][1] = *(const u32x4*)(sp + 8);
-        }
-    }
+    u32x4 X[MREP][2];
 #pragma unroll
     for (int i = 0; i < MREP; ++i) {
         const int m = mrow + i * 16;
-        const int mm = m < m_limit ? m : 0;
         float v[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[j * 4 + r] = apply_act_t<true, Y4_ACT_MISH>(fmaf(acc[i][j][r], sc[j * 4 + r], sh[j * 4 + r]));
         if (p.res) {
-            const T* rp = (const T*)p.res + (int64_t)mm * p.res_cstride + p.res_coff + chb;
 #pragma unroll
-            for (int c = 0; c < 16; c += 8) {
+            for (int c = 0; c < 2; ++c) {
                 float rv[8];
-                E::load_chunk(rp + c, rv);
+                E::load_chunk(&pf.res[i][c], rv);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[c + e] += rv[e];
+                for (int e = 0; e < 8; ++e) v[c * 8 + e] += rv[e];
             }
         }
         E::store_chunk(&X[i][0], v);
@@ -166,10 +180,10 @@ __device__ __forceinline__ void chain_epilogue(const ConvK& p, const char* lds_w
     // CFG (compile time, so that each shape gets its own register allocation): 1 = one 64-channel tail,
     // 2 = two 64-channel tails, 3 = a 64- then a 128-channel tail
     if constexpr (CFG == 1) {
-        chain_step<DT, MREP, 4, true, false>(p, p.tail[0], lds_w, X, X2, mrow, m_limit, lane);
+        chain_step<DT, MREP, 4, true, false>(p, p.tail[0], lds_w, X, pf.x2, mrow, m_limit, lane);
     } else {
-        chain_step<DT, MREP, 4, false, false>(p, p.tail[0], lds_w, X, X2, mrow, m_limit, lane);
-        chain_step<DT, MREP, CFG == 2 ? 4 : 8, true, true>(p, p.tail[1], lds_w + ChainLds<CFG>::T0, X, X2, mrow, m_limit, lane);
+        chain_step<DT, MREP, 4, false, false>(p, p.tail[0], lds_w, X, pf.x2, mrow, m_limit, lane);
+        chain_step<DT, MREP, CFG == 2 ? 4 : 8, true, true>(p, p.tail[1], lds_w + ChainLds<CFG>::T0, X, pf.x2, mrow, m_limit, lane);
     }
 }
 

@@ -64,7 +64,11 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
-    if constexpr (CHAIN != 0) chain_stage_weights<CHAIN, WM * WN>(p, smem + SN * STAGE, __builtin_amdgcn_readfirstlane(wave), lane);
+    ChainPrefetch<CHAIN != 0 ? MREP : 1> chain_pf;
+    if constexpr (CHAIN != 0) {
+        chain_stage_weights<CHAIN, WM * WN>(p, smem + SN * STAGE, __builtin_amdgcn_readfirstlane(wave), lane);
+        chain_prefetch<DT, MREP, CHAIN>(p, chain_pf, m0 + wm * WPX + (lane & 15), p.M, lane);
+    }
 
     // ---- staging set-up: this thread copies physical chunk slot `q` of rows r0 + j*RPI.
     // Loads are buffer_load_dwordx4 ... lds through two raw buffer descriptors (activations, weights): the
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     if constexpr (CHAIN) {
         // chained 1x1 convs consume the tile straight from the accumulators (conv_chain.h)
         static_assert(WN == 1 && BN == 64 && DT != Y4_F32, "chain head: one wave column over all 64 channels, 16-bit");
-        chain_epilogue<DT, MREP, CHAIN>(p, smem + SN * STAGE, acc, m0 + wm * WPX + frow, p.M, lane);
+        chain_epilogue<DT, MREP, CHAIN>(p, smem + SN * STAGE, acc, chain_pf, m0 + wm * WPX + frow, p.M, lane);
     } else {
         const int chb = n0 + wn * WCH + fg * CPL;       // this lane's first channel
         const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.cout_store);
