@@ -8,7 +8,7 @@ from tests.test_gpu_forward import _setup
 size, n, dtype = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 cfg, plan, ws, imgs, eng = _setup(size, 3, n, dtype, seed=6)
 heads = eng.forward_heads(imgs)
-idxs = (5, 6, 7, 8, 12, 13, 14, 15, 16, 17)
+idxs = (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17)
 ref = {i: eng.conv_output(i, n) for i in idxs}
 print("chains", eng.set_chain_fusion(True))
 fh = eng.forward_heads(imgs)

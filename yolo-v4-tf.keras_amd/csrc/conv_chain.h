@@ -187,4 +187,91 @@ __device__ __forceinline__ void chain_epilogue(const ConvK& p, const char* lds_w
     }
 }
 
+// ---- split-head chain (CFG 4: 32-channel tail, CFG 5: 64-channel tail) ---------------------------------------------
+// Head = the fused CSP pair (route conv | main-in conv, one 1x1 GEMM with 128 output rows, custom_layers.py:58-60);
+// tail = the 1x1 conv that reads the main-in half (the residual block's first conv, :36, or csp's bottleneck conv).
+// One wave column over all 128 rows: lane group g holds fused rows 32g .. 32g+31, i.e. groups 0,1 the route
+// channels and groups 2,3 the 64 main-in channels.  The tail's K is laid over all four groups (4 k-steps of 32) with
+// ZERO weights in the route groups' slots (pack_tail_split_kernel) -- twice the MFMAs of a dense K = 64, on a GEMM
+// that is 3 % of the head's work, and no cross-lane traffic.  Both head halves are stored (they have later readers).
+template <int CFG> struct ChainSplitLds {
+    static constexpr int NREP2 = CFG == 4 ? 2 : 4;
+    static constexpr int BYTES = 4 * NREP2 * 1024;
+};
+template <int CFG, int NWAVES>
+__device__ __forceinline__ void chain_split_stage_weights(const ConvK& p, char* lds, int wave, int lane) {
+    const __amdgpu_buffer_rsrc_t r0 = make_rsrc(p.tail[0].w, ChainSplitLds<CFG>::BYTES);
+    for (int u = wave; u < ChainSplitLds<CFG>::BYTES / 1024; u += NWAVES)
+        buffer_load16_lds(r0, lds + __builtin_amdgcn_readfirstlane(u * 1024), u * 1024 + lane * 16, 0);
+}
+
+template <int DT, int MREP, int CFG>
+__device__ __forceinline__ void chain_split_epilogue(const ConvK& p, const char* lds_w, f32x4 (&acc)[MREP][8], int mrow,
+                                                     int m_limit, int lane) {
+    using E = Elem<DT>;
+    using T = typename E::type;
+    constexpr int NREP2 = ChainSplitLds<CFG>::NREP2, CPL2 = 4 * NREP2;
+    const int fg = lane >> 4, chb = fg * 32;
+    const bool second = chb >= p.split;                 // this lane's rows belong to the main-in conv -> out2
+    T* const obase = (T*)(second ? p.out2 : p.out) + (second ? p.out2_coff + chb - p.split : p.out_coff + chb);
+    const int ocs = second ? p.out2_cstride : p.out_cstride;
+    float sc[32], sh[32];
+    chain_load_affine<32>(p.scale, p.shift, chb, sc, sh);
+    u32x4 X[MREP][4];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = mrow + i * 16;
+        float v[32];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j * 4 + r] = apply_act_t<true, Y4_ACT_MISH>(fmaf(acc[i][j][r], sc[j * 4 + r], sh[j * 4 + r]));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) E::store_chunk(&X[i][c], v + c * 8);
+        if (m < m_limit) {
+            T* op = obase + (int64_t)m * ocs;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *(u32x4*)(op + c * 8) = X[i][c];
+        }
+    }
+    f32x4 acc2[MREP][NREP2];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP2; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u32x4* const wf = (const u32x4*)lds_w + lane;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        u32x4 w[NREP2];
+#pragma unroll
+        for (int j = 0; j < NREP2; ++j) w[j] = wf[(s * NREP2 + j) * 64];
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP2; ++j) Mma<DT>::run(acc2[i][j], w[j], X[i][s]);
+    }
+    const ChainTail& t = p.tail[0];
+    const int chb2 = fg * CPL2;
+    float sc2[CPL2], sh2[CPL2];
+    chain_load_affine<CPL2>(t.scale, t.shift, chb2, sc2, sh2);
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = mrow + i * 16;
+        float v[CPL2];
+#pragma unroll
+        for (int j = 0; j < NREP2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j * 4 + r] = apply_act_t<true, Y4_ACT_MISH>(fmaf(acc2[i][j][r], sc2[j * 4 + r], sh2[j * 4 + r]));
+        if (m < m_limit) {
+            T* op = (T*)p.fin + (int64_t)m * p.fin_cstride + p.fin_coff + chb2;
+#pragma unroll
+            for (int c = 0; c < CPL2; c += 8) {
+                u32x4 pk;
+                E::store_chunk(&pk, v + c);
+                *(u32x4*)(op + c) = pk;
+            }
+        }
+    }
+}
+
 }  // namespace y4

@@ -64,8 +64,10 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
-    ChainPrefetch<CHAIN != 0 ? MREP : 1> chain_pf;
-    if constexpr (CHAIN != 0) {
+    ChainPrefetch<(CHAIN != 0 && CHAIN < 4) ? MREP : 1> chain_pf;
+    if constexpr (CHAIN >= 4) {
+        chain_split_stage_weights<CHAIN, WM * WN>(p, smem + SN * STAGE, __builtin_amdgcn_readfirstlane(wave), lane);
+    } else if constexpr (CHAIN != 0) {
         chain_stage_weights<CHAIN, WM * WN>(p, smem + SN * STAGE, __builtin_amdgcn_readfirstlane(wave), lane);
         chain_prefetch<DT, MREP, CHAIN>(p, chain_pf, m0 + wm * WPX + (lane & 15), p.M, lane);
     }
@@ -265,7 +267,10 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     }
 
     // ---- epilogue (conv_common.h): scale/shift, activation, residual, packed converts, slice / upsampled / split store
-    if constexpr (CHAIN) {
+    if constexpr (CHAIN >= 4) {
+        static_assert(WN == 1 && BN == 128 && DT != Y4_F32, "split chain head: one wave column over the 128 fused rows, 16-bit");
+        chain_split_epilogue<DT, MREP, CHAIN>(p, smem + SN * STAGE, acc, m0 + wm * WPX + frow, p.M, lane);
+    } else if constexpr (CHAIN != 0) {
         // chained 1x1 convs consume the tile straight from the accumulators (conv_chain.h)
         static_assert(WN == 1 && BN == 64 && DT != Y4_F32, "chain head: one wave column over all 64 channels, 16-bit");
         chain_epilogue<DT, MREP, CHAIN>(p, smem + SN * STAGE, acc, chain_pf, m0 + wm * WPX + frow, p.M, lane);
@@ -314,7 +319,8 @@ struct TileCfg {
     X(29, 112, 128, 1, 4, 128, 2) \
     X(30, 192, 256, 2, 4, 128, 12) \
     X(31, 256, 256, 2, 4, 128, 12) \
-    X(32, 224, 256, 2, 4, 128, 12)
+    X(32, 224, 256, 2, 4, 128, 12) \
+    X(33, 128, 128, 4, 1, 128, 2)
 
 #define Y4_TILE_ROW(id, bm, bn, wm, wn, bkb, nst) {bm, bn, wm, wn, bkb, nst},
 static const TileCfg kTiles[] = {Y4_TILES(Y4_TILE_ROW)};
@@ -324,7 +330,8 @@ int conv_tile_count() { return kNumTiles; }
 
 template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0>
 static int launch_cfg(const ConvK& k, hipStream_t stream) {
-    constexpr int lds = (NST == 12 ? 2 : NST) * (BM + BN) * BKB + (CHAIN ? ChainLds<CHAIN ? CHAIN : 1>::BYTES : 0);
+    constexpr int lds = (NST == 12 ? 2 : NST) * (BM + BN) * BKB +
+                        (CHAIN >= 4 ? ChainSplitLds<CHAIN >= 4 ? CHAIN : 4>::BYTES : (CHAIN ? ChainLds<(CHAIN && CHAIN < 4) ? CHAIN : 1>::BYTES : 0));
     auto kern = conv_igemm_kernel<DT, BM, BN, WM, WN, BKB, NST, CHAIN>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
@@ -338,13 +345,21 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
 
 constexpr int F32_TILES = 12;
 
-// chain heads: the tiles with one wave column over 64 channels
-static bool chain_tile(int tile) { return tile == 3 || tile == 4 || tile == 15; }
+// chain heads: the tiles with one wave column over 64 channels (33: over the 128 rows of a split head)
+static bool chain_tile(int tile, bool split) { return split ? tile == 33 : (tile == 3 || tile == 4 || tile == 15); }
 
 template <int DT>
 static int launch_dt(int tile, const ConvK& k, hipStream_t s) {
     if (k.ntail > 0) {
         if constexpr (DT != Y4_F32) {
+            if (k.split > 0) {
+                if (tile == 33) {
+                    if (k.tail[0].cout == 32) return launch_cfg<DT, 128, 128, 4, 1, 128, 2, 4>(k, s);
+                    return launch_cfg<DT, 128, 128, 4, 1, 128, 2, 5>(k, s);
+                }
+                set_error("conv2d: tile id %d cannot head a split chain", tile);
+                return Y4_EINVAL;
+            }
             const int cfg = k.ntail == 1 ? 1 : (k.tail[1].cout == 64 ? 2 : 3);
 #define Y4_CHAIN_CASE(CFG)                                                                   \
     case CFG:                                                                                \
@@ -424,7 +439,18 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
     k.ksize = d->ksize; k.stride = d->stride; k.pad = d->ksize == 3 ? 1 : 0;
     k.act = d->act; k.upsample = d->upsample; k.out_f32 = d->out_f32;
     const int cout_pad = (int)round_up(d->cout, COUT_PAD);
-    if (chain && chain->ntail > 0) {
+    const bool split_chain = chain && chain->ntail > 0 && d->out2;
+    if (split_chain) {
+        Y4_REQUIRE(d->dtype != Y4_F32 && d->cout == 128 && d->split == 64 && d->cin % 64 == 0 && d->ksize == 1 && d->act == Y4_ACT_MISH &&
+                       chain->ntail == 1 && chain->fin && chain->fin_cstride % epc == 0 && chain->fin_coff % epc == 0 &&
+                       chain->tail[0].w && chain->tail[0].scale && chain->tail[0].shift && !chain->tail[0].src2 &&
+                       (chain->tail[0].cout == 32 || chain->tail[0].cout == 64),
+                   Y4_EINVAL, "conv2d: bad split-chain description");
+        k.ntail = 1; k.store_x = 1;
+        k.fin = (char*)chain->fin; k.fin_cstride = chain->fin_cstride; k.fin_coff = chain->fin_coff;
+        k.tail[0].w = (const char*)chain->tail[0].w; k.tail[0].scale = chain->tail[0].scale; k.tail[0].shift = chain->tail[0].shift;
+        k.tail[0].cout = chain->tail[0].cout;
+    } else if (chain && chain->ntail > 0) {
         Y4_REQUIRE(d->dtype != Y4_F32 && d->cout == 64 && d->act == Y4_ACT_MISH && !d->upsample && !d->out_f32 && !d->out2 &&
                        chain->ntail <= 2 && chain->fin && chain->fin_cstride % epc == 0 && chain->fin_coff % epc == 0,
                    Y4_EINVAL, "conv2d: bad chain description");
@@ -440,8 +466,8 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
             k.tail[t].cout = ct.cout;
         }
     }
-    int tile = d->tile ? d->tile : (k.ntail > 0 ? (d->cin % (128 / es) == 0 ? 3 : 4) : conv_pick_tile(d->dtype, k.M, d->cin, d->cout));
-    Y4_REQUIRE(k.ntail == 0 || chain_tile(tile), Y4_EINVAL, "conv2d: tile id %d cannot head a chain", tile);
+    int tile = d->tile ? d->tile : (split_chain ? 33 : k.ntail > 0 ? (d->cin % (128 / es) == 0 ? 3 : 4) : conv_pick_tile(d->dtype, k.M, d->cin, d->cout));
+    Y4_REQUIRE(k.ntail == 0 || chain_tile(tile, split_chain), Y4_EINVAL, "conv2d: tile id %d cannot head this chain", tile);
     Y4_REQUIRE(tile >= 1 && tile <= kNumTiles, Y4_EINVAL, "conv2d: tile id %d out of range", tile);
     const TileCfg& tc = kTiles[tile - 1];
     Y4_REQUIRE(tile_ok(tc, d->dtype, d->cin, cout_pad), Y4_EINVAL,
@@ -506,6 +532,33 @@ __global__ void pack_tail_kernel(const float* __restrict__ w, typename Elem<DT>:
         const int ci = src * 64 + 16 * g + 8 * s + e;
         out[idx] = Elem<DT>::st(w[ch2 * cin + ci]);
     }
+}
+
+// Split-head variant (conv_chain.h): K = the head's 128 fused rows in 4 k-steps, zeros in the route half.
+// out[((s*NREP2 + j2)*64 + lane)][e] = (lane>>4) >= 2 ? W[ch2][((lane>>4) - 2)*32 + 8*s + e] : 0
+template <int DT>
+__global__ void pack_tail_split_kernel(const float* __restrict__ w, typename Elem<DT>::type* __restrict__ out, int cout) {
+    const int total = cout * 128, nrep2 = cout / 16, cpl2 = cout / 4;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 7, lane = (idx >> 3) & 63;
+        const int r = idx >> 9;
+        const int j2 = r % nrep2, s = r / nrep2;
+        const int i = lane & 15, g = lane >> 4;
+        const int ch2 = (i >> 2) * cpl2 + j2 * 4 + (i & 3);
+        out[idx] = Elem<DT>::st(g >= 2 ? w[ch2 * 64 + (g - 2) * 32 + 8 * s + e] : 0.f);
+    }
+}
+
+int pack_tail_split_weights(int dtype, int cout, const float* oihw, void* packed, hipStream_t stream) {
+    Y4_REQUIRE((cout == 32 || cout == 64) && oihw && packed, Y4_EINVAL, "pack_tail_split_weights: cout %d", cout);
+    const int blocks = (cout * 128 + 255) / 256;
+    switch (dtype) {
+        case Y4_BF16: hipLaunchKernelGGL(pack_tail_split_kernel<Y4_BF16>, dim3(blocks), dim3(256), 0, stream, oihw, (uint16_t*)packed, cout); break;
+        case Y4_F16: hipLaunchKernelGGL(pack_tail_split_kernel<Y4_F16>, dim3(blocks), dim3(256), 0, stream, oihw, (_Float16*)packed, cout); break;
+        default: set_error("pack_tail_split_weights: 16-bit dtypes only (got %d)", dtype); return Y4_EINVAL;
+    }
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
 }
 
 int pack_tail_weights(int dtype, int cout, int cin, const float* oihw, void* packed, hipStream_t stream) {

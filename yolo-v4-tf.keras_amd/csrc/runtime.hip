@@ -54,6 +54,7 @@ struct Layer {
     int extra_rows = 0;    // rows appended by a fused partner
     size_t w_off, scale_off, shift_off;   // byte offsets in the wts workspace
     bool has_tail = false;                // a chain can run this 1x1 conv as a tail: its weights are also kept in
+    bool tail_split = false;              // ... laid over a split head's 128 fused rows (pack_tail_split_weights)
     size_t tail_off = 0;                  // fragment order (pack_tail_weights) at this offset
 };
 
@@ -62,6 +63,7 @@ struct Layer {
 struct Chain {
     int head, tail[2];      // op indices (tail[1] = -1 for a 2-conv chain)
     bool store_x;           // the head's output has other consumers and is still written
+    bool split = false;     // head = a fused CSP pair (route | main-in), one tail reading the main-in half
     bool enabled = true;    // y4_autotune turns a run off when its separate kernels measure faster
     int tile = 0;           // the head's tile when it runs chained (0 = heuristic); Op::tile stays the unfused choice
 };
@@ -267,6 +269,20 @@ void find_chains(y4_ctx& c) {
     for (int i = 0; i + 1 < nops; ++i) {
         const Op& a = c.ops[i];
         const Op& b = c.ops[i + 1];
+        if (a.kind == OP_CONV && b.kind == OP_CONV && a.conv2 >= 0 && b.conv2 < 0) {
+            // fused CSP pair (64 + 64 rows over a 64-channel input) -> the 1x1 conv on its main-in half
+            const Layer& la = c.layers[a.conv];
+            const Layer& lb = c.layers[b.conv];
+            if (la.d.ksize == 1 && la.d.cin % 64 == 0 && la.d.cout == 64 && a.split == 64 && la.d.act == Y4_ACT_MISH && !a.has_res &&
+                lb.d.ksize == 1 && lb.d.cin == 64 && (lb.d.cout == 32 || lb.d.cout == 64) && lb.d.act == Y4_ACT_MISH && !b.has_res &&
+                !b.upsample && !b.out_f32 && same_view(b.in, a.out2) && !c.layers[b.conv].has_tail) {
+                Chain ch{i, {i + 1, -1}, true};
+                ch.split = true;
+                c.layers[b.conv].has_tail = c.layers[b.conv].tail_split = true;
+                c.chains.push_back(ch);
+            }
+            continue;
+        }
         if (a.kind != OP_CONV || b.kind != OP_CONV || a.conv2 >= 0 || b.conv2 >= 0) continue;
         const Layer& la = c.layers[a.conv];
         const Layer& lb = c.layers[b.conv];
@@ -317,7 +333,7 @@ void layout(y4_ctx& c) {
         L.w_off = off; off = align256(off + wbytes);
         L.scale_off = off; off = align256(off + rows * 4);
         L.shift_off = off; off = align256(off + rows * 4);
-        if (L.has_tail) { L.tail_off = off; off = align256(off + (size_t)L.d.cout * L.d.cin * c.es); }
+        if (L.has_tail) { L.tail_off = off; off = align256(off + (size_t)L.d.cout * (L.tail_split ? 128 : L.d.cin) * c.es); }
     }
     c.wts_bytes = off;
 }
@@ -558,7 +574,9 @@ int y4_pack_weights(y4_handle h, const float* blob, size_t n_floats, void* strea
         } else {
             if (int r = pack_conv_weights(h->cfg.dtype, L.d.cout, L.d.cin, L.d.ksize, w, wdst, s)) return r;
             if (L.has_tail)
-                if (int r = pack_tail_weights(h->cfg.dtype, L.d.cout, L.d.cin, w, h->wts + L.tail_off, s)) return r;
+                if (int r = L.tail_split ? pack_tail_split_weights(h->cfg.dtype, L.d.cout, w, h->wts + L.tail_off, s)
+                                         : pack_tail_weights(h->cfg.dtype, L.d.cout, L.d.cin, w, h->wts + L.tail_off, s))
+                    return r;
         }
     }
     h->weights_ready = true;
