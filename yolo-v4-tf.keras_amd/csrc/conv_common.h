@@ -89,48 +89,64 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_then_barrier() {
 }
 
 
+// ---- channel <-> lane layout of a wave's accumulator tile ("chunked"): within the wave's block of 16*NREP channels
+// starting at `chw`, lane group g = lane>>4 owns, for c = 0 .. NREP/2-1, the 8 channels chw + (4c + g)*8 .. +7:
+// fragment 2c holds the first four of them (rows g*4 + r), fragment 2c+1 the other four.  So
+//   * every 16-byte NHWC store/load instruction of a wave covers 64 contiguous bytes per pixel (4 lane groups), and
+//   * chunk c of a lane IS the B operand of v_mfma_*_16x16x32 for k-step c in the NATURAL K order
+//     (channel 32c + 8g + e), which is what lets conv_chain.h feed a following 1x1 conv from registers with
+//     bit-identical results.
+// The assignment is applied as a row permutation when the weight tile is staged (conv_igemm.hip, b_off).
+__device__ __forceinline__ int chunk_channel(int chw, int c, int fg) { return chw + (c * 4 + fg) * 8; }
+
 // ---- epilogue shared by the conv kernels: y = act(acc*scale + shift) (+ residual) -> NHWC slice store
 // (optionally 2x2 replicated, optionally split over two output views).  `mrow` is this lane's output pixel index
-// for fragment 0 (fragment i is 16 pixels further), pixels >= m_limit are not stored, `chb` is the lane's first
-// channel.  FULL (block-uniform): no per-row / per-chunk predicates at all.
+// for fragment 0 (fragment i is 16 pixels further), pixels >= m_limit are not stored, `chw` is the first channel of
+// the wave's block.  FULL (block-uniform): no per-row / per-chunk predicates at all.
 template <int DT, int MREP, int NREP, int ACT, bool FULL>
 __device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[MREP][NREP], const float* sc,
-                                                   const float* sh, int mrow, int m_limit, int chb) {
+                                                   const float* sh, int mrow, int m_limit, int chw, int fg) {
     using E = Elem<DT>;
     using T = typename E::type;
     constexpr int EPC = E::EPC;
-    constexpr int CPL = 4 * NREP;
+    constexpr int NC = NREP / 2;
     constexpr bool FAST = (DT != Y4_F32);
+    static_assert(NREP % 2 == 0, "chunked layout: fragments come in pairs");
     const int HoWo = p.Ho * p.Wo;
-    // split output: a lane's CPL channels never straddle `split` (both are multiples of CPL)
-    const bool second = p.split > 0 && chb >= p.split;
-    char* const out_ptr = second ? p.out2 : p.out;
-    const int out_cs = second ? p.out2_cstride : p.out_cstride;
-    const int out_co = (second ? p.out2_coff - p.split : p.out_coff) + chb;
-    const T* const res_base = (const T*)p.res + (int64_t)mrow * p.res_cstride + p.res_coff + chb;
+    // per chunk: its first channel, and where it goes (a chunk never straddles `split`: both are multiples of 8)
+    int ch[NC], ooff[NC];
+    bool second[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        ch[c] = chunk_channel(chw, c, fg);
+        second[c] = p.split > 0 && ch[c] >= p.split;
+        ooff[c] = second[c] ? p.out2_coff + ch[c] - p.split : p.out_coff + ch[c];
+    }
 #pragma unroll
     for (int i = 0; i < MREP; ++i) {
         const int m = mrow + i * 16;
         if (!FULL && m >= m_limit) continue;
-        float v[CPL];
+        float v[NC * 8];
 #pragma unroll
         for (int j = 0; j < NREP; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = j * 4 + r;
-                v[c] = apply_act_t<FAST, ACT>(fmaf(acc[i][j][r], sc[c], sh[c]));
+                const int k = j * 4 + r;                     // = chunk (j>>1), element (j&1)*4 + r
+                v[k] = apply_act_t<FAST, ACT>(fmaf(acc[i][j][r], sc[k], sh[k]));
             }
         if (p.res) {
-            const T* rp = res_base + (int64_t)(i * 16) * p.res_cstride;
+            const T* rp = (const T*)p.res + (int64_t)m * p.res_cstride + p.res_coff;
 #pragma unroll
-            for (int c = 0; c < CPL; c += EPC) {
-                if (FULL || chb + c < p.cout_store) {
-                    float rv[EPC];
-                    E::load_chunk(rp + c, rv);
+            for (int c = 0; c < NC; ++c)
+                if (FULL || ch[c] < p.cout_store) {
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[c + e] += rv[e];
+                    for (int e0 = 0; e0 < 8; e0 += EPC) {
+                        float rv[EPC];
+                        E::load_chunk(rp + ch[c] + e0, rv);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) v[c * 8 + e0 + e] += rv[e];
+                    }
                 }
-            }
         }
         int64_t pix[4];
         int npix = 1;
@@ -146,47 +162,57 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[
         }
         if (p.out_f32) {
             for (int u = 0; u < npix; ++u) {
-                float* op = (float*)out_ptr + pix[u] * out_cs + out_co;
 #pragma unroll
-                for (int c = 0; c < CPL; c += 4)
-                    if (FULL || chb + c < p.cout_store) Elem<Y4_F32>::store_chunk(op + c, v + c);
+                for (int c = 0; c < NC; ++c)
+                    if (FULL || ch[c] < p.cout_store) {
+                        float* op = (float*)(second[c] ? p.out2 : p.out) + pix[u] * (second[c] ? p.out2_cstride : p.out_cstride) + ooff[c];
+                        Elem<Y4_F32>::store_chunk(op, v + c * 8);
+                        Elem<Y4_F32>::store_chunk(op + 4, v + c * 8 + 4);
+                    }
             }
         } else {
-            u32x4 packed[CPL / EPC];
+            u32x4 packed[NC * 8 / EPC];
 #pragma unroll
-            for (int c = 0; c < CPL; c += EPC) E::store_chunk(&packed[c / EPC], v + c);
+            for (int k = 0; k < NC * 8; k += EPC) E::store_chunk(&packed[k / EPC], v + k);
             for (int u = 0; u < npix; ++u) {
-                T* op = (T*)out_ptr + pix[u] * out_cs + out_co;
 #pragma unroll
-                for (int c = 0; c < CPL; c += EPC)
-                    if (FULL || chb + c < p.cout_store) *(u32x4*)(op + c) = packed[c / EPC];
+                for (int c = 0; c < NC; ++c)
+                    if (FULL || ch[c] < p.cout_store) {
+                        T* op = (T*)(second[c] ? p.out2 : p.out) + pix[u] * (second[c] ? p.out2_cstride : p.out_cstride) + ooff[c];
+#pragma unroll
+                        for (int e0 = 0; e0 < 8; e0 += EPC) *(u32x4*)(op + e0) = packed[(c * 8 + e0) / EPC];
+                    }
             }
         }
     }
 }
 
 template <int DT, int MREP, int NREP>
-__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP][NREP], int mrow, int m_limit, int chb,
-                                              bool full) {
-    constexpr int CPL = 4 * NREP;
-    float sc[CPL], sh[CPL];
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP][NREP], int mrow, int m_limit, int chw,
+                                              int fg, bool full) {
+    constexpr int NC = NREP / 2;
+    float sc[NC * 8], sh[NC * 8];
 #pragma unroll
-    for (int c = 0; c < CPL; c += 4) {
-        const f32x4 s4 = *(const f32x4*)(p.scale + chb + c);
-        const f32x4 h4 = *(const f32x4*)(p.shift + chb + c);
+    for (int c = 0; c < NC; ++c) {
+        const int ch = chunk_channel(chw, c, fg);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { sc[c + e] = s4[e]; sh[c + e] = h4[e]; }
+        for (int h = 0; h < 8; h += 4) {
+            const f32x4 s4 = *(const f32x4*)(p.scale + ch + h);
+            const f32x4 h4 = *(const f32x4*)(p.shift + ch + h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sc[c * 8 + h + e] = s4[e]; sh[c * 8 + h + e] = h4[e]; }
+        }
     }
     // the activation and the mask mode are compile-time inside; one uniform switch outside the pixel loop
     if (p.act == Y4_ACT_MISH) {
-        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, true>(p, acc, sc, sh, mrow, m_limit, chb);
-        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, false>(p, acc, sc, sh, mrow, m_limit, chb);
+        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, true>(p, acc, sc, sh, mrow, m_limit, chw, fg);
+        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, false>(p, acc, sc, sh, mrow, m_limit, chw, fg);
     } else if (p.act == Y4_ACT_LEAKY) {
-        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LEAKY, true>(p, acc, sc, sh, mrow, m_limit, chb);
-        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LEAKY, false>(p, acc, sc, sh, mrow, m_limit, chb);
+        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LEAKY, true>(p, acc, sc, sh, mrow, m_limit, chw, fg);
+        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LEAKY, false>(p, acc, sc, sh, mrow, m_limit, chw, fg);
     } else {
-        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, true>(p, acc, sc, sh, mrow, m_limit, chb);
-        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, false>(p, acc, sc, sh, mrow, m_limit, chb);
+        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, true>(p, acc, sc, sh, mrow, m_limit, chw, fg);
+        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, false>(p, acc, sc, sh, mrow, m_limit, chw, fg);
     }
 }
 

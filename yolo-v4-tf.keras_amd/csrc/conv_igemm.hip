@@ -64,12 +64,10 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
-    ChainPrefetch<(CHAIN != 0 && CHAIN < 4) ? MREP : 1> chain_pf;
-    if constexpr (CHAIN >= 4) {
-        chain_split_stage_weights<CHAIN, WM * WN>(p, smem + SN * STAGE, __builtin_amdgcn_readfirstlane(wave), lane);
-    } else if constexpr (CHAIN != 0) {
+    ChainPrefetch<CHAIN != 0 ? MREP : 1> chain_pf;
+    if constexpr (CHAIN != 0) {
         chain_stage_weights<CHAIN, WM * WN>(p, smem + SN * STAGE, __builtin_amdgcn_readfirstlane(wave), lane);
-        chain_prefetch<DT, MREP, CHAIN>(p, chain_pf, m0 + wm * WPX + (lane & 15), p.M, lane);
+        if constexpr (!ChainShape<CHAIN>::SPLIT) chain_prefetch<DT, MREP, CHAIN>(p, chain_pf, m0 + wm * WPX + (lane & 15), p.M, lane);
     }
 
     // ---- staging set-up: this thread copies physical chunk slot `q` of rows r0 + j*RPI.
@@ -96,10 +94,10 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
         const int row = B_PART ? (r0 % BN) : (r0 + j * RPI);
-        // LDS row (wave block, fragment jn, MFMA row i = g*4 + r)  <-  channel g*CPL + jn*4 + r
+        // LDS row (wave block, fragment jn, MFMA row i = g*4 + r)  <-  channel of the chunked layout (conv_common.h)
         const int wb = row / WCH, pr = row - wb * WCH;
         const int jn = pr >> 4, i = pr & 15, g = i >> 2, r = i & 3;
-        const int ch = n0 + wb * WCH + g * CPL + jn * 4 + r;
+        const int ch = chunk_channel(n0 + wb * WCH, jn >> 1, g) + (jn & 1) * 4 + r;
         b_off[j] = (ch * p.K + ((q ^ swz<CPR>(row)) * EPC)) * ES;
     }
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
@@ -267,17 +265,14 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     }
 
     // ---- epilogue (conv_common.h): scale/shift, activation, residual, packed converts, slice / upsampled / split store
-    if constexpr (CHAIN >= 4) {
-        static_assert(WN == 1 && BN == 128 && DT != Y4_F32, "split chain head: one wave column over the 128 fused rows, 16-bit");
-        chain_split_epilogue<DT, MREP, CHAIN>(p, smem + SN * STAGE, acc, m0 + wm * WPX + frow, p.M, lane);
-    } else if constexpr (CHAIN != 0) {
+    if constexpr (CHAIN != 0) {
         // chained 1x1 convs consume the tile straight from the accumulators (conv_chain.h)
-        static_assert(WN == 1 && BN == 64 && DT != Y4_F32, "chain head: one wave column over all 64 channels, 16-bit");
+        static_assert(WN == 1 && BN == 16 * ChainShape<CHAIN>::HEAD_NREP && DT != Y4_F32,
+                      "chain head: one wave column over all its output channels, 16-bit");
         chain_epilogue<DT, MREP, CHAIN>(p, smem + SN * STAGE, acc, chain_pf, m0 + wm * WPX + frow, p.M, lane);
     } else {
-        const int chb = n0 + wn * WCH + fg * CPL;       // this lane's first channel
         const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.cout_store);
-        conv_epilogue<DT, MREP, NREP>(p, acc, m0 + wm * WPX + frow, p.M, chb, full);
+        conv_epilogue<DT, MREP, NREP>(p, acc, m0 + wm * WPX + frow, p.M, n0 + wn * WCH, fg, full);
     }
 }
 
@@ -330,8 +325,7 @@ int conv_tile_count() { return kNumTiles; }
 
 template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0>
 static int launch_cfg(const ConvK& k, hipStream_t stream) {
-    constexpr int lds = (NST == 12 ? 2 : NST) * (BM + BN) * BKB +
-                        (CHAIN >= 4 ? ChainSplitLds<CHAIN >= 4 ? CHAIN : 4>::BYTES : (CHAIN ? ChainLds<(CHAIN && CHAIN < 4) ? CHAIN : 1>::BYTES : 0));
+    constexpr int lds = (NST == 12 ? 2 : NST) * (BM + BN) * BKB + (CHAIN ? ChainShape<CHAIN ? CHAIN : 1>::LDS_BYTES : 0);
     auto kern = conv_igemm_kernel<DT, BM, BN, WM, WN, BKB, NST, CHAIN>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
@@ -516,53 +510,24 @@ int pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw
     return Y4_OK;
 }
 
-// 1x1 conv weights (cout, cin, 1, 1) -> MFMA A fragments in the chain's K order (conv_chain.h):
-// out[((src*2 + s)*NREP2 + j2)*64 + lane][e] = W[ch2][src*64 + 16*(lane>>4) + 8*s + e],
-// ch2 = (i>>2)*CPL2 + j2*4 + (i&3), i = lane & 15, NREP2 = cout/16, CPL2 = cout/4.
+// 1x1 conv weights (cout, cin, 1, 1) -> ready-made MFMA A fragments for conv_chain.h (natural K order, chunked
+// output-channel layout): out[((s*NREP2 + j2)*64 + lane)][e] = W[ch2][32*s + 8*(lane>>4) + e],
+// ch2 = ((j2>>1)*4 + (i>>2))*8 + (j2&1)*4 + (i&3), i = lane & 15, NREP2 = cout/16, s < cin/32.
 template <int DT>
 __global__ void pack_tail_kernel(const float* __restrict__ w, typename Elem<DT>::type* __restrict__ out, int cout, int cin) {
-    const int total = cout * cin, nrep2 = cout / 16, cpl2 = cout / 4;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int e = idx & 7, lane = (idx >> 3) & 63;
-        int r = idx >> 9;
-        const int j2 = r % nrep2; r /= nrep2;
-        const int s = r & 1, src = r >> 1;
-        const int i = lane & 15, g = lane >> 4;
-        const int ch2 = (i >> 2) * cpl2 + j2 * 4 + (i & 3);
-        const int ci = src * 64 + 16 * g + 8 * s + e;
-        out[idx] = Elem<DT>::st(w[ch2 * cin + ci]);
-    }
-}
-
-// Split-head variant (conv_chain.h): K = the head's 128 fused rows in 4 k-steps, zeros in the route half.
-// out[((s*NREP2 + j2)*64 + lane)][e] = (lane>>4) >= 2 ? W[ch2][((lane>>4) - 2)*32 + 8*s + e] : 0
-template <int DT>
-__global__ void pack_tail_split_kernel(const float* __restrict__ w, typename Elem<DT>::type* __restrict__ out, int cout) {
-    const int total = cout * 128, nrep2 = cout / 16, cpl2 = cout / 4;
+    const int total = cout * cin, nrep2 = cout / 16;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int e = idx & 7, lane = (idx >> 3) & 63;
         const int r = idx >> 9;
         const int j2 = r % nrep2, s = r / nrep2;
         const int i = lane & 15, g = lane >> 4;
-        const int ch2 = (i >> 2) * cpl2 + j2 * 4 + (i & 3);
-        out[idx] = Elem<DT>::st(g >= 2 ? w[ch2 * 64 + (g - 2) * 32 + 8 * s + e] : 0.f);
+        const int ch2 = ((j2 >> 1) * 4 + (i >> 2)) * 8 + (j2 & 1) * 4 + (i & 3);
+        out[idx] = Elem<DT>::st(w[ch2 * cin + 32 * s + 8 * g + e]);
     }
-}
-
-int pack_tail_split_weights(int dtype, int cout, const float* oihw, void* packed, hipStream_t stream) {
-    Y4_REQUIRE((cout == 32 || cout == 64) && oihw && packed, Y4_EINVAL, "pack_tail_split_weights: cout %d", cout);
-    const int blocks = (cout * 128 + 255) / 256;
-    switch (dtype) {
-        case Y4_BF16: hipLaunchKernelGGL(pack_tail_split_kernel<Y4_BF16>, dim3(blocks), dim3(256), 0, stream, oihw, (uint16_t*)packed, cout); break;
-        case Y4_F16: hipLaunchKernelGGL(pack_tail_split_kernel<Y4_F16>, dim3(blocks), dim3(256), 0, stream, oihw, (_Float16*)packed, cout); break;
-        default: set_error("pack_tail_split_weights: 16-bit dtypes only (got %d)", dtype); return Y4_EINVAL;
-    }
-    Y4_CHECK_HIP(hipGetLastError());
-    return Y4_OK;
 }
 
 int pack_tail_weights(int dtype, int cout, int cin, const float* oihw, void* packed, hipStream_t stream) {
-    Y4_REQUIRE((cout == 64 || cout == 128) && (cin == 64 || cin == 128) && oihw && packed, Y4_EINVAL,
+    Y4_REQUIRE((cout == 32 || cout == 64 || cout == 128) && (cin == 64 || cin == 128) && oihw && packed, Y4_EINVAL,
                "pack_tail_weights: cout %d cin %d", cout, cin);
     const int blocks = (cout * cin + 255) / 256;
     switch (dtype) {

@@ -21,7 +21,6 @@ struct ConvChainDesc {
 };
 int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream, const ConvChainDesc* chain = nullptr);
 int pack_tail_weights(int dtype, int cout, int cin, const float* oihw, void* packed, hipStream_t stream);
-int pack_tail_split_weights(int dtype, int cout, const float* oihw, void* packed, hipStream_t stream);   // cout*128 elements
 int conv_tile_count();
 int conv_pick_tile(int dtype, int M, int cin, int cout);
 int pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw, void* packed, hipStream_t stream);

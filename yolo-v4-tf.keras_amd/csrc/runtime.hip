@@ -54,7 +54,6 @@ struct Layer {
     int extra_rows = 0;    // rows appended by a fused partner
     size_t w_off, scale_off, shift_off;   // byte offsets in the wts workspace
     bool has_tail = false;                // a chain can run this 1x1 conv as a tail: its weights are also kept in
-    bool tail_split = false;              // ... laid over a split head's 128 fused rows (pack_tail_split_weights)
     size_t tail_off = 0;                  // fragment order (pack_tail_weights) at this offset
 };
 
@@ -278,7 +277,7 @@ void find_chains(y4_ctx& c) {
                 !b.upsample && !b.out_f32 && same_view(b.in, a.out2) && !c.layers[b.conv].has_tail) {
                 Chain ch{i, {i + 1, -1}, true};
                 ch.split = true;
-                c.layers[b.conv].has_tail = c.layers[b.conv].tail_split = true;
+                c.layers[b.conv].has_tail = true;
                 c.chains.push_back(ch);
             }
             continue;
@@ -333,7 +332,7 @@ void layout(y4_ctx& c) {
         L.w_off = off; off = align256(off + wbytes);
         L.scale_off = off; off = align256(off + rows * 4);
         L.shift_off = off; off = align256(off + rows * 4);
-        if (L.has_tail) { L.tail_off = off; off = align256(off + (size_t)L.d.cout * (L.tail_split ? 128 : L.d.cin) * c.es); }
+        if (L.has_tail) { L.tail_off = off; off = align256(off + (size_t)L.d.cout * L.d.cin * c.es); }
     }
     c.wts_bytes = off;
 }
@@ -574,9 +573,7 @@ int y4_pack_weights(y4_handle h, const float* blob, size_t n_floats, void* strea
         } else {
             if (int r = pack_conv_weights(h->cfg.dtype, L.d.cout, L.d.cin, L.d.ksize, w, wdst, s)) return r;
             if (L.has_tail)
-                if (int r = L.tail_split ? pack_tail_split_weights(h->cfg.dtype, L.d.cout, w, h->wts + L.tail_off, s)
-                                         : pack_tail_weights(h->cfg.dtype, L.d.cout, L.d.cin, w, h->wts + L.tail_off, s))
-                    return r;
+                if (int r = pack_tail_weights(h->cfg.dtype, L.d.cout, L.d.cin, w, h->wts + L.tail_off, s)) return r;
         }
     }
     h->weights_ready = true;

@@ -58,6 +58,11 @@ class Yolov4(object):
         self.plan = build_plan(self.img_size[0], self.num_classes)
         self.engine = Engine(self.num_classes, self.config, max_batch=self._max_batch, dtype=self._dtype,
                              device=self._device)
+        if self._dtype != 'f32':
+            # bit-identical scheduling choices (tests/test_gpu_forward.py): convs 0+1 in one kernel, CSP runs chained
+            if self.img_size[0] <= 640:
+                self.engine.set_stem_fusion(True)
+            self.engine.set_chain_fusion(True)
         self.yolo_model = _KerasLikeModel(self.engine.forward_heads, 'yolo_model')
         print(f"nms iou: {self.config['iou_threshold']} score: {self.config['score_threshold']}")
         self.inference_model = _KerasLikeModel(self.engine.predict, 'inference_model')
