@@ -52,6 +52,22 @@ def cpu_baseline(size, ncls, ws, cfg, sample_n=8, runs=3):
                       f"+ NumPy decode/NMS (oracle/), after 1 warm-up run; {dt:.1f} s of CPU work"}
 
 
+def measured_traffic(args, fused_stem, chained, launches):
+    """HBM bytes per conv_igemm launch from the committed PMC passes (profiles/r01/hbm_traffic_v3.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes),
+    or None when this run's configuration is not the profiled one.  Counters cannot be read from inside the process."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "hbm_traffic_v3.json")
+    try:
+        prof = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    want = {"size": args.size, "classes": args.classes, "batch": args.batch, "dtype": args.dtype,
+            "stem_fusion": bool(fused_stem), "chain_fusion": bool(chained)}
+    if prof.get("config") != want or launches <= 0:
+        return None
+    return round(prof["conv_igemm_hbm_bytes_per_step"] / launches)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +157,10 @@ def main():
         total_ms = sum(ms for _, ms in ops)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.dtype]
+        # tails that run inside their head's kernel: heads are reported as -tile by the autotuner / tile file
+        tails_of = {2: 1, 5: 2, 9: 1, 12: 1, 14: 2}
+        fused_tails = sum(n_t for head, n_t in tails_of.items() if chained and (tiles is None or tiles[head] <= 0))
+        conv_launches = launches - (first_conv - 1) - fused_tails
         line = {
             "metric": "images/sec end-to-end predict() at 608x608 batch 32; conv MFMA %peak",
             "value": round(n_img / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -154,8 +174,9 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "sharding": f"batch split over {world} rank(s), no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
-                         "kernel": "conv_igemm_kernel (convs %d..109, %d launches/step)" % (first_conv, launches - (first_conv - 1) - (5 if chained else 0)),
+                         "frac": round(achieved / peak, 4),
+                         "traffic": measured_traffic(args, fused_stem, chained, conv_launches),
+                         "kernel": "conv_igemm_kernel (convs %d..109, %d launches/step)" % (first_conv, conv_launches),
                          "flops_per_step": conv_flops, "kernel_ms_per_step": round(conv_ms, 4),
                          "timed_steps": nrec},
             "breakdown_ms_per_step": {"conv_igemm": round(conv_ms, 4), ("stem_c0+c1_fused" if fused_stem else "stem_c0"): round(other.get("c0", 0.0), 4),

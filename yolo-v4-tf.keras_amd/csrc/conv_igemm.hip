@@ -9,9 +9,11 @@
 //   copied HBM/L2 -> LDS with global_load_lds (16 B per lane, no VGPR round trip).
 //   Weights are pre-packed [cout_pad][kh][kw][cin] so their K-tile rows are contiguous too.
 // The weight fragment is the MFMA *A* operand and the pixel fragment the *B* operand, so the accumulator
-// layout is D[row = channel][col = pixel]: every lane ends up holding 4*NREP CONSECUTIVE channels of one
-// pixel (the channel <-> MFMA-row assignment is free; it is applied as a row permutation when staging the
-// weight tile), i.e. the NHWC epilogue is 16-byte vector loads/stores with no LDS transpose.
+// layout is D[row = channel][col = pixel]: every lane ends up holding runs of 8 CONSECUTIVE channels of one
+// pixel (the channel <-> MFMA-row assignment is free; the "chunked" assignment of conv_common.h is applied as a
+// row permutation when staging the weight tile), i.e. the NHWC epilogue is 16-byte vector loads/stores with no
+// LDS transpose, 64 contiguous bytes per pixel per instruction, and a lane's chunks are ready-made MFMA B
+// operands for a chained 1x1 conv (conv_chain.h).
 // LDS rows are BKB (64|128) bytes with the 16-byte chunk index XOR-swizzled by the row so that every
 // ds_read_b128 lane group hits 16 distinct slots; global_load_lds writes LDS lane-linearly, so the
 // swizzle is applied to the per-lane SOURCE address and again on the fragment read (same involution).
