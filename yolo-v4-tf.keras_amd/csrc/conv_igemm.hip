@@ -48,8 +48,6 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     static_assert(SN >= 2 && SN <= 4 && (SN == 2 || !B_PART), "deep pipelines need uniform weight loads per wave");
     static_assert((SN - 2) * LPT <= 63, "vmcnt field");
     static_assert(!PHASED || (NT == 512 && KSTEPS == 2), "phased schedule: 8 waves, 128-byte K rows");
-    using E = Elem<DT>;
-    using T = typename E::type;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 

@@ -80,7 +80,6 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
                                                         int out_cstride, int out_coff, int act, FastDiv div_hw,
                                                         FastDiv div_w, int tiles_per_wave) {
     using E = Elem<DT>;
-    using T = typename E::type;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane & 15, g = lane >> 4;
     const u32x4 wf0 = wfrag[lane], wf1 = wfrag[64 + lane];
