@@ -152,6 +152,41 @@ def test_batch_rows_independent_of_batch_size():
     eng.close()
 
 
+def test_full_size_properties():
+    """BASELINE.json's headline configuration (608x608, 80 classes, batch 32, bf16, fusions on) through size-independent
+    properties: the step is deterministic (two runs bit-equal), every image of the batch equals that image run alone
+    (images are independent units, so any batch sharding over ranks gives the same rows), the fused schedule equals the
+    plain one bit for bit, detections are well-formed (scores descending and above the threshold, boxes ordered,
+    padding zeroed, kept indices unique per class), and a batch of all-zero images matches between batch and single."""
+    import torch
+    size, ncls, n = 608, 80, 32
+    cfg, plan, ws, imgs, eng = _setup(size, ncls, n, "bf16", seed=7)
+    imgs[5] = 0.0
+    dev = torch.from_numpy(imgs).to(eng.device)
+    plain = [o.cpu().numpy() for o in eng.predict_device(dev)]
+    eng.set_stem_fusion(True)
+    assert eng.set_chain_fusion(True) == 5
+    run1 = [o.cpu().numpy() for o in eng.predict_device(dev)]
+    run2 = [o.cpu().numpy() for o in eng.predict_device(dev)]
+    for a, b, c in zip(run1, run2, plain):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    boxes, scores, classes, valid, kept = run1
+    thr = cfg["score_threshold"]
+    assert valid.min() >= 0 and valid.max() <= 100 and valid.sum() > 0
+    for b in range(n):
+        v = int(valid[b])
+        assert np.all(np.diff(scores[b, :v]) <= 0) and np.all(scores[b, :v] > thr)
+        assert np.all(boxes[b, :v, 2] >= boxes[b, :v, 0]) and np.all(boxes[b, :v, 3] >= boxes[b, :v, 1])
+        assert not boxes[b, v:].any() and not scores[b, v:].any() and not classes[b, v:].any()
+        pairs = list(zip(kept[b, :v].tolist(), classes[b, :v].tolist()))
+        assert len(set(pairs)) == v and all(0 <= c < ncls for _, c in pairs)
+    for i in (0, 5, 17, 31):
+        one = [o.cpu().numpy() for o in eng.predict_device(dev[i:i + 1])]
+        for a, b in zip(run1, one):
+            assert np.array_equal(a[i:i + 1], b), i
+    eng.close()
+
+
 def test_scheduling_knobs_do_not_change_results():
     """Autotuned tiles, restored tiles and sub-batched early layers are speed knobs: outputs stay bit-identical."""
     cfg, plan, ws, imgs, eng = _setup(160, 3, 3, "bf16", seed=4)
