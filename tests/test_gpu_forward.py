@@ -210,7 +210,7 @@ def test_scheduling_knobs_do_not_change_results():
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-@pytest.mark.parametrize("size,n", [(160, 3), (416, 2), (608, 1), (640, 1)])
+@pytest.mark.parametrize("size,n", [(96, 5), (160, 3), (416, 2), (608, 1), (640, 1)])
 def test_stem_fusion_is_bit_identical(dtype, size, n):
     """convs 0+1 as one kernel (conv 0's output kept in LDS): same MFMA products summed in the same order as the two
     separate kernels, so conv 1's output, the heads and the detections must be bit-identical -- including the
@@ -242,7 +242,7 @@ def test_stem_fusion_is_bit_identical(dtype, size, n):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-@pytest.mark.parametrize("size,n", [(160, 3), (416, 2), (608, 1)])
+@pytest.mark.parametrize("size,n", [(96, 5), (160, 3), (416, 2), (608, 1)])
 def test_chain_fusion_is_bit_identical(dtype, size, n):
     """3x3+Add -> 1x1 (-> 1x1 over the concat) and CSP-pair -> 1x1 runs as one kernel each: a chained conv issues the
     same MFMAs on the same 16-bit inputs in the same order as its own kernel would, so every materialised tensor, the
