@@ -148,8 +148,9 @@ int y4_set_stem_fusion(y4_handle h, int on);
 /* Scheduling knob (16-bit dtypes): run each "3x3 conv + residual Add -> 1x1 conv [-> 1x1 conv over
  * Concatenate([., route])]" run of the CSP stages with 64-channel blocks (reference custom_layers.py:41-44, :66-69
  * and the conv that follows csp_block, :104/:109) as ONE kernel: the intermediate tensors stay in registers instead
- * of going through HBM.  Same products, fp32-accumulated in a different order: results agree with the unfused path
- * to 16-bit rounding, not bitwise.  Returns the number of fused runs (>= 0) when turned on, Y4_OK when turned off,
+ * of going through HBM; likewise "3x3 conv + Add -> the next block's 1x1 conv" of the 128- and 256-channel stages
+ * through an LDS-resident tile.  A chained conv issues the same MFMAs on the same inputs in the same order as its own
+ * kernel: results are bit-identical.  Returns the number of fusable runs (>= 0) when turned on, Y4_OK when turned off,
  * a negative Y4_E* code on error.  While on, y4_get_conv_output of a conv inside a run (not its last) reads a
  * tensor that is not materialised.  y4_autotune then also decides per run, by measurement, whether it executes as
  * one kernel or as separate ones; y4_get_tiles reports a fused run's head conv as MINUS its tile id (y4_set_tiles

@@ -44,6 +44,10 @@ struct ConvK {
     ChainTail tail[2];
     char* fin;
     int fin_cstride, fin_coff;
+    // LDS pair (pair != 0, conv_igemm.hip): this conv's output tile is also kept in LDS and a following 1x1 conv
+    // (tail[0]: ordinary packed weights, `tail_w_bytes` long; output view `fin`) runs from there in the same kernel
+    int pair, tail_act;
+    unsigned tail_w_bytes;
 };
 
 template <int CPR> __device__ __forceinline__ int swz(int row) {
@@ -103,9 +107,13 @@ __device__ __forceinline__ int chunk_channel(int chw, int c, int fg) { return ch
 // (optionally 2x2 replicated, optionally split over two output views).  `mrow` is this lane's output pixel index
 // for fragment 0 (fragment i is 16 pixels further), pixels >= m_limit are not stored, `chw` is the first channel of
 // the wave's block.  FULL (block-uniform): no per-row / per-chunk predicates at all.
-template <int DT, int MREP, int NREP, int ACT, bool FULL>
+// XL: the packed 16-bit tile is ALSO written to LDS at `xl` as Cout/64 consecutive [BM rows][128 B] panels (row =
+// pixel `xrow` + 16 i of the block, chunk index XOR-swizzled by the row like a staged activation tile), i.e. in the
+// layout the K loop reads its pixel operand from -- the input of a following 1x1 conv (LDS pair).
+template <int DT, int MREP, int NREP, int ACT, bool FULL, bool XL = false>
 __device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[MREP][NREP], const float* sc,
-                                                   const float* sh, int mrow, int m_limit, int chw, int fg) {
+                                                   const float* sh, int mrow, int m_limit, int chw, int fg,
+                                                   char* xl = nullptr, int xrow = 0, int xpanel = 0) {
     using E = Elem<DT>;
     using T = typename E::type;
     constexpr int EPC = E::EPC;
@@ -174,7 +182,14 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[
             u32x4 packed[NC * 8 / EPC];
 #pragma unroll
             for (int k = 0; k < NC * 8; k += EPC) E::store_chunk(&packed[k / EPC], v + k);
-            for (int u = 0; u < npix; ++u) {
+            if constexpr (XL) {
+                static_assert(!XL || EPC == 8, "LDS pair: 16-bit dtypes");
+                const int row = xrow + i * 16;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    *(u32x4*)(xl + (ch[c] >> 6) * xpanel + row * 128 + ((((ch[c] & 63) >> 3) ^ (row & 7)) * 16)) = packed[c];
+            }
+            for (int u = 0; u < (XL ? 0 : npix); ++u) {     // XL: the tile goes out from LDS after the tail (pair_store_tile)
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
                     if (FULL || ch[c] < p.cout_store) {
@@ -187,9 +202,9 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[
     }
 }
 
-template <int DT, int MREP, int NREP>
+template <int DT, int MREP, int NREP, bool XL = false>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP][NREP], int mrow, int m_limit, int chw,
-                                              int fg, bool full) {
+                                              int fg, bool full, char* xl = nullptr, int xrow = 0, int xpanel = 0) {
     constexpr int NC = NREP / 2;
     float sc[NC * 8], sh[NC * 8];
 #pragma unroll
@@ -205,14 +220,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP]
     }
     // the activation and the mask mode are compile-time inside; one uniform switch outside the pixel loop
     if (p.act == Y4_ACT_MISH) {
-        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, true>(p, acc, sc, sh, mrow, m_limit, chw, fg);
-        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, false>(p, acc, sc, sh, mrow, m_limit, chw, fg);
+        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, true, XL>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
+        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, false, XL>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
     } else if (p.act == Y4_ACT_LEAKY) {
-        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LEAKY, true>(p, acc, sc, sh, mrow, m_limit, chw, fg);
-        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LEAKY, false>(p, acc, sc, sh, mrow, m_limit, chw, fg);
+        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LEAKY, true, XL>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
+        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LEAKY, false, XL>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
     } else {
-        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, true>(p, acc, sc, sh, mrow, m_limit, chw, fg);
-        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, false>(p, acc, sc, sh, mrow, m_limit, chw, fg);
+        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, true, XL>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
+        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, false, XL>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
+    }
+}
+
+// LDS pair: the head conv's tile, kept in LDS by the XL epilogue, goes to its HBM view (lane re-reads the chunks it wrote).
+template <int DT, int MREP, int NREP>
+__device__ __forceinline__ void pair_store_tile(const ConvK& p, const char* xl, int xrow, int xpanel, int mrow, int m_limit,
+                                                int chw, int fg) {
+    using T = typename Elem<DT>::type;
+    constexpr int NC = NREP / 2;
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = mrow + i * 16, row = xrow + i * 16;
+        if (m >= m_limit) continue;
+        T* op = (T*)p.out + (int64_t)m * p.out_cstride + p.out_coff;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = chunk_channel(chw, c, fg);
+            *(u32x4*)(op + ch) = *(const u32x4*)(xl + (ch >> 6) * xpanel + row * 128 + ((((ch & 63) >> 3) ^ (row & 7)) * 16));
+        }
     }
 }
 

@@ -22,7 +22,7 @@
 
 namespace y4 {
 
-template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0>
+template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0, bool PAIR = false>
 __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel(const ConvK p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int ES = (DT == Y4_F32) ? 4 : 2;
@@ -270,6 +270,66 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         static_assert(WN == 1 && BN == 16 * ChainShape<CHAIN>::HEAD_NREP && DT != Y4_F32,
                       "chain head: one wave column over all its output channels, 16-bit");
         chain_epilogue<DT, MREP, CHAIN>(p, smem + SN * STAGE, acc, chain_pf, m0 + wm * WPX + frow, p.M, lane);
+    } else if constexpr (PAIR) {
+        // ---- LDS pair: this conv's tile stays in LDS (as BN/64 panels in the K loop's pixel-operand layout) and the
+        // following 1x1 conv (BN -> BN channels, ordinary packed weights) runs from it with the same fragment reads and
+        // the same K order as its own kernel would -- bit-identical, one launch and one HBM read less.
+        static_assert(BKB == 128 && DT != Y4_F32 && SN == 2 && !PHASED && !B_PART, "LDS pair: plain 2-stage, 128-byte rows");
+        constexpr int XPANEL = BM * 128, NK2 = BN / 64, XBYTES = NK2 * XPANEL, W2STAGE = BN * 128;
+        __syncthreads();                                   // every wave is done with the stage buffers X overwrites
+        char* const xl = smem;
+        const int xrow = wm * WPX + frow, mrow = m0 + xrow, chw = wn * WCH;
+        // tail weights: same row permutation as the head's weight tile, K2 = BN contiguous elements per channel row
+        int b2_off[B_IT];
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const int row = r0 + j * RPI;
+            const int wb = row / WCH, pr = row - wb * WCH;
+            const int jn = pr >> 4, i = pr & 15, g = i >> 2, r = i & 3;
+            const int ch = chunk_channel(wb * WCH, jn >> 1, g) + (jn & 1) * 4 + r;
+            b2_off[j] = (ch * BN + ((q ^ swz<CPR>(row)) * EPC)) * ES;
+        }
+        const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(p.tail[0].w, p.tail_w_bytes);
+        auto stage_w2 = [&](int buf, int kt) {
+#pragma unroll
+            for (int j = 0; j < B_IT; ++j)
+                buffer_load16_lds(rs_w2, smem + XBYTES + buf * W2STAGE + wave_lds + j * (NT * 16), b2_off[j], kt * BKB);
+        };
+        stage_w2(0, 0);                                    // its round trip hides under the head's epilogue
+        conv_epilogue<DT, MREP, NREP, true>(p, acc, mrow, p.M, chw, fg, m0 + BM <= p.M, xl, xrow, XPANEL);
+        __syncthreads();                                   // X complete (ds_write -> lgkmcnt(0) -> barrier)
+        f32x4 acc2[MREP][NREP];
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < NK2; ++kt) {
+            wait_vmcnt_then_barrier<0>();
+            if (kt + 1 < NK2) stage_w2((kt + 1) & 1, kt + 1);
+            const char* sx = xl + kt * XPANEL + (wm * WPX) * BKB;
+            const char* sw = smem + XBYTES + (kt & 1) * W2STAGE + (wn * WCH) * BKB;
+            u32x4 xf[KSTEPS][MREP], wf[KSTEPS][NREP];
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) xf[kk][i] = *(const u32x4*)(sx + i * 16 * BKB + xo[kk]);
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) wf[kk][j] = *(const u32x4*)(sw + j * 16 * BKB + xo[kk]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk)
+#pragma unroll
+                for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                    for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc2[i][j], wf[kk][j], xf[kk][i]);
+        }
+        // tail epilogue through the ordinary path: a ConvK that describes the 1x1 conv's output side
+        ConvK p2 = p;
+        p2.scale = p.tail[0].scale; p2.shift = p.tail[0].shift; p2.act = p.tail_act; p2.res = nullptr;
+        p2.out = p.fin; p2.out_cstride = p.fin_cstride; p2.out_coff = p.fin_coff;
+        p2.cout_store = p.tail[0].cout; p2.upsample = 0; p2.out_f32 = 0; p2.split = 0;
+        conv_epilogue<DT, MREP, NREP>(p2, acc2, mrow, p.M, chw, fg, (m0 + BM <= p.M) && BN <= p2.cout_store);
+        pair_store_tile<DT, MREP, NREP>(p, xl, xrow, XPANEL, mrow, p.M, chw, fg);
     } else {
         const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.cout_store);
         conv_epilogue<DT, MREP, NREP>(p, acc, m0 + wm * WPX + frow, p.M, n0 + wn * WCH, fg, full);
@@ -323,10 +383,13 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 int conv_tile_count() { return kNumTiles; }
 
-template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0>
+template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0, bool PAIR = false>
 static int launch_cfg(const ConvK& k, hipStream_t stream) {
-    constexpr int lds = (NST == 12 ? 2 : NST) * (BM + BN) * BKB + (CHAIN ? ChainShape<CHAIN ? CHAIN : 1>::LDS_BYTES : 0);
-    auto kern = conv_igemm_kernel<DT, BM, BN, WM, WN, BKB, NST, CHAIN>;
+    constexpr int lds_main = (NST == 12 ? 2 : NST) * (BM + BN) * BKB + (CHAIN ? ChainShape<CHAIN ? CHAIN : 1>::LDS_BYTES : 0);
+    constexpr int lds_pair = PAIR ? (BN / 64) * BM * 128 + 2 * BN * 128 : 0;     // tile panels + two weight stages of the tail
+    constexpr int lds = lds_main > lds_pair ? lds_main : lds_pair;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = conv_igemm_kernel<DT, BM, BN, WM, WN, BKB, NST, CHAIN, PAIR>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         Y4_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -342,8 +405,28 @@ constexpr int F32_TILES = 12;
 // chain heads: the tiles with one wave column over 64 channels (33: over the 128 rows of a split head)
 static bool chain_tile(int tile, bool split) { return split ? tile == 33 : (tile == 3 || tile == 4 || tile == 15); }
 
+// LDS-pair heads: 128-byte K rows, 2 stages, one channel tile over all of Cout (128 or 256), tile + tail stages in LDS
+static bool pair_tile(int tile) {
+    switch (tile) { case 1: case 8: case 20: case 24: case 25: case 29: case 13: case 19: case 21: case 22: return true; }
+    return false;
+}
+
 template <int DT>
 static int launch_dt(int tile, const ConvK& k, hipStream_t s) {
+    if (k.pair) {
+        if constexpr (DT != Y4_F32) {
+#define Y4_PAIR_CASE(id, bm, bn, wm, wn) case id: return launch_cfg<DT, bm, bn, wm, wn, 128, 2, 0, true>(k, s);
+            switch (tile) {
+                Y4_PAIR_CASE(1, 128, 128, 2, 2) Y4_PAIR_CASE(8, 64, 128, 1, 4) Y4_PAIR_CASE(20, 96, 128, 2, 2)
+                Y4_PAIR_CASE(24, 160, 128, 2, 2) Y4_PAIR_CASE(25, 192, 128, 2, 2) Y4_PAIR_CASE(29, 112, 128, 1, 4)
+                Y4_PAIR_CASE(13, 128, 256, 2, 4) Y4_PAIR_CASE(19, 192, 256, 2, 4) Y4_PAIR_CASE(21, 96, 256, 2, 4)
+                Y4_PAIR_CASE(22, 160, 256, 2, 4)
+            }
+#undef Y4_PAIR_CASE
+        }
+        set_error("conv2d: tile id %d cannot head an LDS pair", tile);
+        return Y4_EINVAL;
+    }
     if (k.ntail > 0) {
         if constexpr (DT != Y4_F32) {
             if (k.split > 0) {
@@ -394,7 +477,8 @@ int conv_pick_tile(int dtype, int M, int cin, int cout) {
     return k128 ? 8 : 9;      // 64x128: more, smaller blocks overlap load / MFMA / store phases best (measured)
 }
 
-int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream, const ConvChainDesc* chain) {
+int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream, const ConvChainDesc* chain,
+                  const ConvPairDesc* pair) {
     Y4_REQUIRE(d && d->in && d->wt && d->out && d->scale && d->shift, Y4_EINVAL, "conv2d: null pointer");
     Y4_REQUIRE(d->dtype >= Y4_F32 && d->dtype <= Y4_F16, Y4_EINVAL, "conv2d: bad dtype %d", d->dtype);
     Y4_REQUIRE(d->ksize == 1 || d->ksize == 3, Y4_EINVAL, "conv2d: ksize %d (only 1 or 3)", d->ksize);
@@ -433,6 +517,16 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
     k.ksize = d->ksize; k.stride = d->stride; k.pad = d->ksize == 3 ? 1 : 0;
     k.act = d->act; k.upsample = d->upsample; k.out_f32 = d->out_f32;
     const int cout_pad = (int)round_up(d->cout, COUT_PAD);
+    if (pair) {
+        Y4_REQUIRE(!chain && d->dtype != Y4_F32 && (d->cout == 128 || d->cout == 256) && pair->cout == d->cout && !d->upsample &&
+                       !d->out_f32 && !d->out2 && pair->w && pair->scale && pair->shift && pair->fin &&
+                       pair->fin_cstride % epc == 0 && pair->fin_coff % epc == 0,
+                   Y4_EINVAL, "conv2d: bad LDS-pair description");
+        k.pair = 1; k.tail_act = pair->act;
+        k.tail[0].w = (const char*)pair->w; k.tail[0].scale = pair->scale; k.tail[0].shift = pair->shift; k.tail[0].cout = pair->cout;
+        k.tail_w_bytes = (unsigned)(round_up(pair->cout, COUT_PAD) * d->cout * es);
+        k.fin = (char*)pair->fin; k.fin_cstride = pair->fin_cstride; k.fin_coff = pair->fin_coff;
+    }
     const bool split_chain = chain && chain->ntail > 0 && d->out2;
     if (split_chain) {
         Y4_REQUIRE(d->dtype != Y4_F32 && d->cout == 128 && d->split == 64 && d->cin % 64 == 0 && d->ksize == 1 && d->act == Y4_ACT_MISH &&
@@ -460,8 +554,9 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
             k.tail[t].cout = ct.cout;
         }
     }
-    int tile = d->tile ? d->tile : (split_chain ? 33 : k.ntail > 0 ? (d->cin % (128 / es) == 0 ? 3 : 4) : conv_pick_tile(d->dtype, k.M, d->cin, d->cout));
+    int tile = d->tile ? d->tile : pair ? (d->cout == 128 ? 20 : 19) : (split_chain ? 33 : k.ntail > 0 ? (d->cin % (128 / es) == 0 ? 3 : 4) : conv_pick_tile(d->dtype, k.M, d->cin, d->cout));
     Y4_REQUIRE(k.ntail == 0 || chain_tile(tile, split_chain), Y4_EINVAL, "conv2d: tile id %d cannot head this chain", tile);
+    Y4_REQUIRE(!pair || (pair_tile(tile) && kTiles[tile - 1].bn == d->cout), Y4_EINVAL, "conv2d: tile id %d cannot head this LDS pair", tile);
     Y4_REQUIRE(tile >= 1 && tile <= kNumTiles, Y4_EINVAL, "conv2d: tile id %d out of range", tile);
     const TileCfg& tc = kTiles[tile - 1];
     Y4_REQUIRE(tile_ok(tc, d->dtype, d->cin, cout_pad), Y4_EINVAL,

@@ -19,7 +19,18 @@ struct ConvChainDesc {
     void* fin;
     int fin_cstride, fin_coff;
 };
-int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream, const ConvChainDesc* chain = nullptr);
+// LDS pair: a following 1x1 conv with as many output channels as the head (128 or 256) runs from the head's tile kept
+// in LDS.  `w` = that conv's ordinary packed weights; d->out is still written.
+struct ConvPairDesc {
+    const void* w;
+    const float* scale;
+    const float* shift;
+    int act, cout;
+    void* fin;
+    int fin_cstride, fin_coff;
+};
+int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream, const ConvChainDesc* chain = nullptr,
+                  const ConvPairDesc* pair = nullptr);
 int pack_tail_weights(int dtype, int cout, int cin, const float* oihw, void* packed, hipStream_t stream);
 int conv_tile_count();
 int conv_pick_tile(int dtype, int M, int cin, int cout);

@@ -63,6 +63,7 @@ struct Chain {
     int head, tail[2];      // op indices (tail[1] = -1 for a 2-conv chain)
     bool store_x;           // the head's output has other consumers and is still written
     bool split = false;     // head = a fused CSP pair (route | main-in), one tail reading the main-in half
+    bool lds_pair = false;  // the tail runs from the head's tile kept in LDS (128/256 channels), not from registers
     bool enabled = true;    // y4_autotune turns a run off when its separate kernels measure faster
     int tile = 0;           // the head's tile when it runs chained (0 = heuristic); Op::tile stays the unfused choice
 };
@@ -305,6 +306,27 @@ void find_chains(y4_ctx& c) {
         if (ch.tail[1] >= 0) c.layers[c.ops[ch.tail[1]].conv].has_tail = true;
         c.chains.push_back(ch);
     }
+    // LDS pairs: conv (128 or 256 output channels) -> 1x1 conv with the same channel count reading exactly that output
+    // (the residual blocks of the 76^2 and 38^2 stages: 3x3 + Add -> the next block's 1x1, custom_layers.py:34-44)
+    auto in_chain = [&](int oi) {
+        for (const Chain& ch : c.chains)
+            if (ch.head == oi || ch.tail[0] == oi || ch.tail[1] == oi) return true;
+        return false;
+    };
+    for (int i = 0; i + 1 < nops; ++i) {
+        const Op& a = c.ops[i];
+        const Op& b = c.ops[i + 1];
+        if (a.kind != OP_CONV || b.kind != OP_CONV || a.conv2 >= 0 || b.conv2 >= 0 || in_chain(i) || in_chain(i + 1)) continue;
+        const Layer& la = c.layers[a.conv];
+        const Layer& lb = c.layers[b.conv];
+        if ((la.d.cout != 128 && la.d.cout != 256) || a.upsample || a.out_f32) continue;
+        if (!(lb.d.ksize == 1 && lb.d.cin == la.d.cout && lb.d.cout == la.d.cout && !b.has_res && !b.upsample && !b.out_f32 &&
+              same_view(b.in, a.out)))
+            continue;
+        Chain ch{i, {i + 1, -1}, true};
+        ch.lds_pair = true;
+        c.chains.push_back(ch);
+    }
 }
 
 void layout(y4_ctx& c) {
@@ -407,6 +429,17 @@ int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s, i
     if (op.has_res) { d.res = buf_ptr(h, op.res, img0); d.res_cstride = op.res.cstride; d.res_coff = op.res.coff; }
     if (op.conv2 >= 0) { d.out2 = buf_ptr(h, op.out2, img0); d.out2_cstride = op.out2.cstride; d.out2_coff = op.out2.coff; d.split = op.split; }
     d.tile = chain ? chain->tile : op.tile;
+    if (chain && chain->lds_pair) {
+        const Op& to = h->ops[chain->tail[0]];
+        const Layer& TL = h->layers[to.conv];
+        ConvPairDesc pd{};
+        pd.w = h->wts + TL.w_off;
+        pd.scale = (const float*)(h->wts + TL.scale_off);
+        pd.shift = (const float*)(h->wts + TL.shift_off);
+        pd.act = TL.d.act; pd.cout = TL.d.cout;
+        pd.fin = buf_ptr(h, to.out, img0); pd.fin_cstride = to.out.cstride; pd.fin_coff = to.out.coff;
+        return conv2d_launch(&d, h->act + h->zero_off, s, nullptr, &pd);
+    }
     if (chain) {
         ConvChainDesc cd{};
         cd.store_x = chain->store_x ? 1 : 0;
