@@ -327,9 +327,9 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         ConvK p2 = p;
         p2.scale = p.tail[0].scale; p2.shift = p.tail[0].shift; p2.act = p.tail_act; p2.res = nullptr;
         p2.out = p.fin; p2.out_cstride = p.fin_cstride; p2.out_coff = p.fin_coff;
-        p2.cout_store = p.tail[0].cout; p2.upsample = 0; p2.out_f32 = 0; p2.split = 0;
+        p2.cout_store = p.tail[0].cout; p2.upsample = 0; p2.out_f32 = p.pair >> 1; p2.split = 0;
         conv_epilogue<DT, MREP, NREP>(p2, acc2, mrow, p.M, chw, fg, (m0 + BM <= p.M) && BN <= p2.cout_store);
-        pair_store_tile<DT, MREP, NREP>(p, xl, xrow, XPANEL, mrow, p.M, chw, fg);
+        if (p.store_x) pair_store_tile<DT, MREP, NREP>(p, xl, xrow, XPANEL, mrow, p.M, chw, fg);
     } else {
         const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.cout_store);
         conv_epilogue<DT, MREP, NREP>(p, acc, m0 + wm * WPX + frow, p.M, n0 + wn * WCH, fg, full);
@@ -518,12 +518,12 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
     k.act = d->act; k.upsample = d->upsample; k.out_f32 = d->out_f32;
     const int cout_pad = (int)round_up(d->cout, COUT_PAD);
     if (pair) {
-        Y4_REQUIRE(!chain && d->dtype != Y4_F32 && (d->cout == 128 || d->cout == 256) && pair->cout == d->cout && !d->upsample &&
+        Y4_REQUIRE(!chain && d->dtype != Y4_F32 && (d->cout == 128 || d->cout == 256) && pair->cout >= 1 && pair->cout <= d->cout && !d->upsample &&
                        !d->out_f32 && !d->out2 && pair->w && pair->scale && pair->shift && pair->fin &&
-                       pair->fin_cstride % epc == 0 && pair->fin_coff % epc == 0,
+                       pair->fin_cstride % (pair->out_f32 ? 4 : epc) == 0 && pair->fin_coff % (pair->out_f32 ? 4 : epc) == 0,
                    Y4_EINVAL, "conv2d: bad LDS-pair description");
-        k.pair = 1; k.tail_act = pair->act;
-        k.tail[0].w = (const char*)pair->w; k.tail[0].scale = pair->scale; k.tail[0].shift = pair->shift; k.tail[0].cout = pair->cout;
+        k.pair = pair->out_f32 ? 3 : 1; k.tail_act = pair->act; k.store_x = pair->store_x;
+        k.tail[0].w = (const char*)pair->w; k.tail[0].scale = pair->scale; k.tail[0].shift = pair->shift; k.tail[0].cout = (int)round_up(pair->cout, 8);
         k.tail_w_bytes = (unsigned)(round_up(pair->cout, COUT_PAD) * d->cout * es);
         k.fin = (char*)pair->fin; k.fin_cstride = pair->fin_cstride; k.fin_coff = pair->fin_coff;
     }

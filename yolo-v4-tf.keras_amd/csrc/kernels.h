@@ -19,13 +19,13 @@ struct ConvChainDesc {
     void* fin;
     int fin_cstride, fin_coff;
 };
-// LDS pair: a following 1x1 conv with as many output channels as the head (128 or 256) runs from the head's tile kept
-// in LDS.  `w` = that conv's ordinary packed weights; d->out is still written.
+// LDS pair: a following 1x1 conv with at most as many output channels as the head (128 or 256) runs from the head's
+// tile kept in LDS.  `w` = that conv's ordinary packed weights; d->out is written only if store_x.
 struct ConvPairDesc {
     const void* w;
     const float* scale;
     const float* shift;
-    int act, cout;
+    int act, cout, out_f32, store_x;
     void* fin;
     int fin_cstride, fin_coff;
 };

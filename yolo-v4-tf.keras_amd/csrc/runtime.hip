@@ -320,10 +320,9 @@ void find_chains(y4_ctx& c) {
         const Layer& la = c.layers[a.conv];
         const Layer& lb = c.layers[b.conv];
         if ((la.d.cout != 128 && la.d.cout != 256) || a.upsample || a.out_f32) continue;
-        if (!(lb.d.ksize == 1 && lb.d.cin == la.d.cout && lb.d.cout == la.d.cout && !b.has_res && !b.upsample && !b.out_f32 &&
-              same_view(b.in, a.out)))
+        if (!(lb.d.ksize == 1 && lb.d.cin == la.d.cout && lb.d.cout <= la.d.cout && !b.has_res && !b.upsample && same_view(b.in, a.out)))
             continue;
-        Chain ch{i, {i + 1, -1}, true};
+        Chain ch{i, {i + 1, -1}, readers(a.out.buf, i + 1, -1)};
         ch.lds_pair = true;
         c.chains.push_back(ch);
     }
@@ -436,7 +435,7 @@ int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s, i
         pd.w = h->wts + TL.w_off;
         pd.scale = (const float*)(h->wts + TL.scale_off);
         pd.shift = (const float*)(h->wts + TL.shift_off);
-        pd.act = TL.d.act; pd.cout = TL.d.cout;
+        pd.act = TL.d.act; pd.cout = TL.d.cout; pd.out_f32 = to.out_f32 ? 1 : 0; pd.store_x = chain->store_x ? 1 : 0;
         pd.fin = buf_ptr(h, to.out, img0); pd.fin_cstride = to.out.cstride; pd.fin_coff = to.out.coff;
         return conv2d_launch(&d, h->act + h->zero_off, s, nullptr, &pd);
     }
