@@ -120,7 +120,7 @@ def main():
     first_conv = 2 if fused_stem else 1
     chained = 0
     if args.dtype != "f32" and not args.no_chain_fusion:
-        chained = eng.set_chain_fusion(True)      # 24 runs of 2-3 convs (CSP stages) -> one conv_igemm launch each
+        chained = eng.set_chain_fusion(True)      # 25 runs of 2-3 convs (CSP stages) -> one conv_igemm launch each
     if args.load_tiles:
         tiles = json.load(open(args.load_tiles))["tiles"]
         eng.set_tiles(tiles)
@@ -158,7 +158,7 @@ def main():
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         # tails that run inside their head's kernel: heads are reported as -tile by the autotuner / tile file
-        tails_of = {2: 1, 5: 2, 9: 1, 12: 1, 14: 2}
+        tails_of = {2: 1, 5: 2, 8: 1, 12: 1, 14: 2, 17: 1}
         tails_of.update({h: 1 for h in list(range(21, 36, 2)) + list(range(42, 57, 2)) + [88, 90, 92]})   # LDS pairs
         fused_tails = sum(n_t for head, n_t in tails_of.items() if chained and (tiles is None or tiles[head] <= 0))
         conv_launches = launches - (first_conv - 1) - fused_tails

@@ -48,6 +48,8 @@ struct ConvK {
     // (tail[0]: ordinary packed weights, `tail_w_bytes` long; output view `fin`) runs from there in the same kernel
     int pair, tail_act;
     unsigned tail_w_bytes;
+    char* fin2;                    // the tail is a fused CSP pair: its rows >= tail_split go to this view
+    int fin2_cstride, fin2_coff, tail_split;
 };
 
 template <int CPR> __device__ __forceinline__ int swz(int row) {

@@ -327,7 +327,8 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         ConvK p2 = p;
         p2.scale = p.tail[0].scale; p2.shift = p.tail[0].shift; p2.act = p.tail_act; p2.res = nullptr;
         p2.out = p.fin; p2.out_cstride = p.fin_cstride; p2.out_coff = p.fin_coff;
-        p2.cout_store = p.tail[0].cout; p2.upsample = 0; p2.out_f32 = p.pair >> 1; p2.split = 0;
+        p2.cout_store = p.tail[0].cout; p2.upsample = 0; p2.out_f32 = p.pair >> 1;
+        p2.split = p.tail_split; p2.out2 = p.fin2; p2.out2_cstride = p.fin2_cstride; p2.out2_coff = p.fin2_coff;
         conv_epilogue<DT, MREP, NREP>(p2, acc2, mrow, p.M, chw, fg, (m0 + BM <= p.M) && BN <= p2.cout_store);
         if (p.store_x) pair_store_tile<DT, MREP, NREP>(p, xl, xrow, XPANEL, mrow, p.M, chw, fg);
     } else {
@@ -526,6 +527,11 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
         k.tail[0].w = (const char*)pair->w; k.tail[0].scale = pair->scale; k.tail[0].shift = pair->shift; k.tail[0].cout = (int)round_up(pair->cout, 8);
         k.tail_w_bytes = (unsigned)(round_up(pair->cout, COUT_PAD) * d->cout * es);
         k.fin = (char*)pair->fin; k.fin_cstride = pair->fin_cstride; k.fin_coff = pair->fin_coff;
+        Y4_REQUIRE(!pair->fin2 || (pair->split > 0 && pair->split % 32 == 0 && pair->split < pair->cout && !pair->out_f32 &&
+                                   pair->fin2_cstride % epc == 0 && pair->fin2_coff % epc == 0),
+                   Y4_EINVAL, "conv2d: bad LDS-pair split description");
+        k.fin2 = (char*)pair->fin2; k.fin2_cstride = pair->fin2_cstride; k.fin2_coff = pair->fin2_coff;
+        k.tail_split = pair->fin2 ? pair->split : 0;
     }
     const bool split_chain = chain && chain->ntail > 0 && d->out2;
     if (split_chain) {

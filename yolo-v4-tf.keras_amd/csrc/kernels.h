@@ -28,6 +28,8 @@ struct ConvPairDesc {
     int act, cout, out_f32, store_x;
     void* fin;
     int fin_cstride, fin_coff;
+    void* fin2;                    // tail = a fused CSP pair (cout = both convs' rows): rows >= split go here
+    int fin2_cstride, fin2_coff, split;
 };
 int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream, const ConvChainDesc* chain = nullptr,
                   const ConvPairDesc* pair = nullptr);

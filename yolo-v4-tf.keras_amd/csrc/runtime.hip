@@ -266,9 +266,32 @@ void find_chains(y4_ctx& c) {
         }
         return false;
     };
+    auto in_chain = [&](int oi) {
+        for (const Chain& ch : c.chains)
+            if (ch.head == oi || ch.tail[0] == oi || ch.tail[1] == oi) return true;
+        return false;
+    };
+    // LDS pairs whose tail is a fused CSP pair: the stride-2 3x3 conv that opens a stage -> that stage's route | main-in
+    // 1x1 GEMM (custom_layers.py:107-108, :112-113 -> :58-60).  Found first: they save more traffic than the
+    // split-head register chain that could start at the same CSP pair.
     for (int i = 0; i + 1 < nops; ++i) {
         const Op& a = c.ops[i];
         const Op& b = c.ops[i + 1];
+        if (a.kind != OP_CONV || b.kind != OP_CONV || a.conv2 >= 0 || b.conv2 < 0) continue;
+        const Layer& la = c.layers[a.conv];
+        const Layer& lb = c.layers[b.conv];
+        if ((la.d.cout != 128 && la.d.cout != 256) || a.upsample || a.out_f32 || a.has_res) continue;
+        if (!(lb.d.ksize == 1 && lb.d.cin == la.d.cout && 2 * lb.d.cout == la.d.cout && b.split == lb.d.cout && !b.has_res &&
+              same_view(b.in, a.out)))
+            continue;
+        Chain ch{i, {i + 1, -1}, readers(a.out.buf, i + 1, -1)};
+        ch.lds_pair = true;
+        c.chains.push_back(ch);
+    }
+    for (int i = 0; i + 1 < nops; ++i) {
+        const Op& a = c.ops[i];
+        const Op& b = c.ops[i + 1];
+        if (in_chain(i) || in_chain(i + 1)) continue;
         if (a.kind == OP_CONV && b.kind == OP_CONV && a.conv2 >= 0 && b.conv2 < 0) {
             // fused CSP pair (64 + 64 rows over a 64-channel input) -> the 1x1 conv on its main-in half
             const Layer& la = c.layers[a.conv];
@@ -308,11 +331,6 @@ void find_chains(y4_ctx& c) {
     }
     // LDS pairs: conv (128 or 256 output channels) -> 1x1 conv with the same channel count reading exactly that output
     // (the residual blocks of the 76^2 and 38^2 stages: 3x3 + Add -> the next block's 1x1, custom_layers.py:34-44)
-    auto in_chain = [&](int oi) {
-        for (const Chain& ch : c.chains)
-            if (ch.head == oi || ch.tail[0] == oi || ch.tail[1] == oi) return true;
-        return false;
-    };
     for (int i = 0; i + 1 < nops; ++i) {
         const Op& a = c.ops[i];
         const Op& b = c.ops[i + 1];
@@ -437,6 +455,10 @@ int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s, i
         pd.shift = (const float*)(h->wts + TL.shift_off);
         pd.act = TL.d.act; pd.cout = TL.d.cout; pd.out_f32 = to.out_f32 ? 1 : 0; pd.store_x = chain->store_x ? 1 : 0;
         pd.fin = buf_ptr(h, to.out, img0); pd.fin_cstride = to.out.cstride; pd.fin_coff = to.out.coff;
+        if (to.conv2 >= 0) {          // the tail is a fused CSP pair: both convs' rows, split over two views
+            pd.cout = 2 * TL.d.cout; pd.split = to.split;
+            pd.fin2 = buf_ptr(h, to.out2, img0); pd.fin2_cstride = to.out2.cstride; pd.fin2_coff = to.out2.coff;
+        }
         return conv2d_launch(&d, h->act + h->zero_off, s, nullptr, &pd);
     }
     if (chain) {
