@@ -246,8 +246,8 @@ def test_stem_fusion_is_bit_identical(dtype, size, n):
 def test_chain_fusion_is_bit_identical(dtype, size, n):
     """3x3+Add -> 1x1 (-> 1x1 over the concat) and CSP-pair -> 1x1 runs as one kernel each: a chained conv issues the
     same MFMAs on the same 16-bit inputs in the same order as its own kernel would, so every materialised tensor, the
-    heads and the detections are bit-identical to the unfused path.  25 runs exist in the plan: four through registers
-    (convs 2+3-4, 5-6-7, 12-13, 14-15-16) and 21 through an LDS-resident tile (3x3+Add -> the next 1x1 in the 76^2 and
+    heads and the detections are bit-identical to the unfused path.  25 runs exist in the plan: three through registers
+    (convs 5-6-7, 12-13, 14-15-16) and 22 through an LDS-resident tile (the CSP pair 2+3 -> 4; 3x3+Add -> the next 1x1 in the 76^2 and
     38^2 stages: 21-22 .. 35-36, 42-43 .. 56-57; the neck's 88-89, 90-91 and 92-93 = raw head 0; the stage openers
     8 -> 9+10 and 17 -> 18+19, whose tail is the fused CSP pair); autotune (which may turn a run off again), restored
     tiles and sub-batching keep that."""

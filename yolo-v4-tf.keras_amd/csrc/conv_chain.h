@@ -5,7 +5,6 @@
 // one 16-byte register quad -- holds channels 32c + 8g .. +7 of pixel q: exactly the B operand of
 // v_mfma_f32_16x16x32 for k-step c of a following 1x1 conv in the NATURAL K order.  So a run
 //     3x3 conv (+ residual Add)  ->  1x1 conv  ->  1x1 conv over Concatenate([that, route])        (CFG 1..3)
-//     fused CSP pair (route | main-in)  ->  1x1 conv on the main-in half                            (CFG 4, 5)
 // (reference custom_layers.py:34-44 residual_block, :47-69 csp_block and the conv after it, :104/:109) executes in
 // one kernel: the intermediate tensors never leave the registers, the concat partner is read from HBM straight into the
 // same fragment layout, the tail weights are ordinary A fragments.  Each chained conv issues the same MFMAs on the same
@@ -35,12 +34,10 @@ __device__ __forceinline__ void chain_load_affine(const float* scale, const floa
 // Shape of a chain (compile time, so that each gets its own register allocation):
 //   CFG 1: head 64 ch -> tail 64          CFG 2: head 64 -> 64 -> (64 | partner 64) -> 64
 //   CFG 3: head 64 -> 64 -> (64 | partner 64) -> 128
-//   CFG 4: split head 64|64 -> tail 32 on the second half      CFG 5: same, tail 64
 template <int CFG> struct ChainShape {
-    static constexpr bool SPLIT = CFG >= 4;
-    static constexpr int HEAD_NREP = SPLIT ? 8 : 4;
+    static constexpr int HEAD_NREP = 4;
     static constexpr int T0_K = 64;
-    static constexpr int T0_COUT = CFG == 4 ? 32 : 64;
+    static constexpr int T0_COUT = 64;
     static constexpr int T1_K = (CFG == 2 || CFG == 3) ? 128 : 0;
     static constexpr int T1_COUT = CFG == 2 ? 64 : (CFG == 3 ? 128 : 0);
     static constexpr int T0_BYTES = T0_COUT * T0_K * 2, T1_BYTES = T1_COUT * T1_K * 2;
@@ -149,30 +146,21 @@ __device__ __forceinline__ void chain_epilogue(const ConvK& p, const char* lds_w
         for (int j = 0; j < HN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[j * 4 + r] = apply_act_t<true, Y4_ACT_MISH>(fmaf(acc[i][j][r], sc[j * 4 + r], sh[j * 4 + r]));
-        if constexpr (!S::SPLIT) {
-            if (p.res) {
+        if (p.res) {
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    float rv[8];
-                    E::load_chunk(&pf.res[i][c], rv);
+            for (int c = 0; c < 2; ++c) {
+                float rv[8];
+                E::load_chunk(&pf.res[i][c], rv);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[c * 8 + e] += rv[e];
-                }
+                for (int e = 0; e < 8; ++e) v[c * 8 + e] += rv[e];
             }
         }
 #pragma unroll
         for (int c = 0; c < HC; ++c) E::store_chunk(&X[i][c], v + c * 8);
-        if (m < m_limit) {
-            if constexpr (S::SPLIT) {        // both halves have later readers: route -> out, main-in -> out2
-                chain_store<DT, 2>(p.out, m, p.out_cstride, p.out_coff, fg, &X[i][0]);
-                chain_store<DT, 2>(p.out2, m, p.out2_cstride, p.out2_coff, fg, &X[i][2]);
-            } else if (p.store_x) {
-                chain_store<DT, 2>(p.out, m, p.out_cstride, p.out_coff, fg, &X[i][0]);
-            }
-        }
+        if (p.store_x && m < m_limit) chain_store<DT, 2>(p.out, m, p.out_cstride, p.out_coff, fg, &X[i][0]);
     }
-    // ---- tail 0: 64 channels (the head's, or a split head's second half) -> T0_COUT
-    constexpr int N0 = S::T0_COUT / 16, XOFF = S::SPLIT ? 2 : 0;
+    // ---- tail 0: the head's 64 channels -> 64
+    constexpr int N0 = S::T0_COUT / 16, XOFF = 0;
     f32x4 a0[MREP][N0];
     chain_gemm<DT, MREP, N0, 2>(lds_w, lane, a0, [&](int i, int s) -> const u32x4& { return X[i][XOFF + s]; });
     float sc0[N0 * 4], sh0[N0 * 4];

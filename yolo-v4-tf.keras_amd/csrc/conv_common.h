@@ -50,6 +50,7 @@ struct ConvK {
     unsigned tail_w_bytes;
     char* fin2;                    // the tail is a fused CSP pair: its rows >= tail_split go to this view
     int fin2_cstride, fin2_coff, tail_split;
+    int tail_k, tail_panel0;       // the tail reads tail_k input channels starting at LDS panel tail_panel0 (64 channels each)
 };
 
 template <int CPR> __device__ __forceinline__ int swz(int row) {
@@ -233,7 +234,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP]
     }
 }
 
-// LDS pair: the head conv's tile, kept in LDS by the XL epilogue, goes to its HBM view (lane re-reads the chunks it wrote).
+// LDS pair: the head conv's tile, kept in LDS by the XL epilogue, goes to its HBM view(s) (lane re-reads the chunks it
+// wrote; a fused CSP pair as head splits them over out / out2 like the ordinary epilogue).
 template <int DT, int MREP, int NREP>
 __device__ __forceinline__ void pair_store_tile(const ConvK& p, const char* xl, int xrow, int xpanel, int mrow, int m_limit,
                                                 int chw, int fg) {
@@ -243,11 +245,13 @@ __device__ __forceinline__ void pair_store_tile(const ConvK& p, const char* xl, 
     for (int i = 0; i < MREP; ++i) {
         const int m = mrow + i * 16, row = xrow + i * 16;
         if (m >= m_limit) continue;
-        T* op = (T*)p.out + (int64_t)m * p.out_cstride + p.out_coff;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int ch = chunk_channel(chw, c, fg);
-            *(u32x4*)(op + ch) = *(const u32x4*)(xl + (ch >> 6) * xpanel + row * 128 + ((((ch & 63) >> 3) ^ (row & 7)) * 16));
+            const bool second = p.split > 0 && ch >= p.split;
+            T* op = second ? (T*)p.out2 + (int64_t)m * p.out2_cstride + p.out2_coff + ch - p.split
+                           : (T*)p.out + (int64_t)m * p.out_cstride + p.out_coff + ch;
+            *(u32x4*)op = *(const u32x4*)(xl + (ch >> 6) * xpanel + row * 128 + ((((ch & 63) >> 3) ^ (row & 7)) * 16));
         }
     }
 }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     ChainPrefetch<CHAIN != 0 ? MREP : 1> chain_pf;
     if constexpr (CHAIN != 0) {
         chain_stage_weights<CHAIN, WM * WN>(p, smem + SN * STAGE, __builtin_amdgcn_readfirstlane(wave), lane);
-        if constexpr (!ChainShape<CHAIN>::SPLIT) chain_prefetch<DT, MREP, CHAIN>(p, chain_pf, m0 + wm * WPX + (lane & 15), p.M, lane);
+        chain_prefetch<DT, MREP, CHAIN>(p, chain_pf, m0 + wm * WPX + (lane & 15), p.M, lane);
     }
 
     // ---- staging set-up: this thread copies physical chunk slot `q` of rows r0 + j*RPI.
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         __syncthreads();                                   // every wave is done with the stage buffers X overwrites
         char* const xl = smem;
         const int xrow = wm * WPX + frow, mrow = m0 + xrow, chw = wn * WCH;
-        // tail weights: same row permutation as the head's weight tile, K2 = BN contiguous elements per channel row
+        // tail weights: same row permutation as the head's weight tile, tail_k contiguous elements per channel row
         int b2_off[B_IT];
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
             const int wb = row / WCH, pr = row - wb * WCH;
             const int jn = pr >> 4, i = pr & 15, g = i >> 2, r = i & 3;
             const int ch = chunk_channel(wb * WCH, jn >> 1, g) + (jn & 1) * 4 + r;
-            b2_off[j] = (ch * BN + ((q ^ swz<CPR>(row)) * EPC)) * ES;
+            b2_off[j] = (ch * p.tail_k + ((q ^ swz<CPR>(row)) * EPC)) * ES;
         }
         const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(p.tail[0].w, p.tail_w_bytes);
         auto stage_w2 = [&](int buf, int kt) {
@@ -303,10 +303,11 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         for (int i = 0; i < MREP; ++i)
 #pragma unroll
             for (int j = 0; j < NREP; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < NK2; ++kt) {
+        const int nk2 = p.tail_k >> 6;                     // K-tiles of the tail: its input is panels tail_panel0 .. +nk2-1
+        for (int kt = 0; kt < nk2; ++kt) {
             wait_vmcnt_then_barrier<0>();
-            if (kt + 1 < NK2) stage_w2((kt + 1) & 1, kt + 1);
-            const char* sx = xl + kt * XPANEL + (wm * WPX) * BKB;
+            if (kt + 1 < nk2) stage_w2((kt + 1) & 1, kt + 1);
+            const char* sx = xl + (p.tail_panel0 + kt) * XPANEL + (wm * WPX) * BKB;
             const char* sw = smem + XBYTES + (kt & 1) * W2STAGE + (wn * WCH) * BKB;
             u32x4 xf[KSTEPS][MREP], wf[KSTEPS][NREP];
 #pragma unroll
@@ -375,8 +376,7 @@ struct TileCfg {
     X(29, 112, 128, 1, 4, 128, 2) \
     X(30, 192, 256, 2, 4, 128, 12) \
     X(31, 256, 256, 2, 4, 128, 12) \
-    X(32, 224, 256, 2, 4, 128, 12) \
-    X(33, 128, 128, 4, 1, 128, 2)
+    X(32, 224, 256, 2, 4, 128, 12)
 
 #define Y4_TILE_ROW(id, bm, bn, wm, wn, bkb, nst) {bm, bn, wm, wn, bkb, nst},
 static const TileCfg kTiles[] = {Y4_TILES(Y4_TILE_ROW)};
@@ -403,8 +403,8 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
 
 constexpr int F32_TILES = 12;
 
-// chain heads: the tiles with one wave column over 64 channels (33: over the 128 rows of a split head)
-static bool chain_tile(int tile, bool split) { return split ? tile == 33 : (tile == 3 || tile == 4 || tile == 15); }
+// chain heads: the tiles with one wave column over 64 channels
+static bool chain_tile(int tile) { return tile == 3 || tile == 4 || tile == 15; }
 
 // LDS-pair heads: 128-byte K rows, 2 stages, one channel tile over all of Cout (128 or 256), tile + tail stages in LDS
 static bool pair_tile(int tile) {
@@ -430,14 +430,6 @@ static int launch_dt(int tile, const ConvK& k, hipStream_t s) {
     }
     if (k.ntail > 0) {
         if constexpr (DT != Y4_F32) {
-            if (k.split > 0) {
-                if (tile == 33) {
-                    if (k.tail[0].cout == 32) return launch_cfg<DT, 128, 128, 4, 1, 128, 2, 4>(k, s);
-                    return launch_cfg<DT, 128, 128, 4, 1, 128, 2, 5>(k, s);
-                }
-                set_error("conv2d: tile id %d cannot head a split chain", tile);
-                return Y4_EINVAL;
-            }
             const int cfg = k.ntail == 1 ? 1 : (k.tail[1].cout == 64 ? 2 : 3);
 #define Y4_CHAIN_CASE(CFG)                                                                   \
     case CFG:                                                                                \
@@ -520,12 +512,15 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
     const int cout_pad = (int)round_up(d->cout, COUT_PAD);
     if (pair) {
         Y4_REQUIRE(!chain && d->dtype != Y4_F32 && (d->cout == 128 || d->cout == 256) && pair->cout >= 1 && pair->cout <= d->cout && !d->upsample &&
-                       !d->out_f32 && !d->out2 && pair->w && pair->scale && pair->shift && pair->fin &&
+                       !d->out_f32 && (!d->out2 || (d->split == 64 && d->cout == 128)) && pair->w && pair->scale && pair->shift && pair->fin &&
                        pair->fin_cstride % (pair->out_f32 ? 4 : epc) == 0 && pair->fin_coff % (pair->out_f32 ? 4 : epc) == 0,
                    Y4_EINVAL, "conv2d: bad LDS-pair description");
         k.pair = pair->out_f32 ? 3 : 1; k.tail_act = pair->act; k.store_x = pair->store_x;
         k.tail[0].w = (const char*)pair->w; k.tail[0].scale = pair->scale; k.tail[0].shift = pair->shift; k.tail[0].cout = (int)round_up(pair->cout, 8);
-        k.tail_w_bytes = (unsigned)(round_up(pair->cout, COUT_PAD) * d->cout * es);
+        // a fused CSP pair as head: the tail reads its main-in half (rows >= split), i.e. the LDS panels from split/64 on
+        k.tail_k = d->out2 ? d->cout - d->split : d->cout;
+        k.tail_panel0 = d->out2 ? d->split / 64 : 0;
+        k.tail_w_bytes = (unsigned)(round_up(pair->cout, COUT_PAD) * k.tail_k * es);
         k.fin = (char*)pair->fin; k.fin_cstride = pair->fin_cstride; k.fin_coff = pair->fin_coff;
         Y4_REQUIRE(!pair->fin2 || (pair->split > 0 && pair->split % 32 == 0 && pair->split < pair->cout && !pair->out_f32 &&
                                    pair->fin2_cstride % epc == 0 && pair->fin2_coff % epc == 0),
@@ -533,18 +528,7 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
         k.fin2 = (char*)pair->fin2; k.fin2_cstride = pair->fin2_cstride; k.fin2_coff = pair->fin2_coff;
         k.tail_split = pair->fin2 ? pair->split : 0;
     }
-    const bool split_chain = chain && chain->ntail > 0 && d->out2;
-    if (split_chain) {
-        Y4_REQUIRE(d->dtype != Y4_F32 && d->cout == 128 && d->split == 64 && d->cin % 64 == 0 && d->ksize == 1 && d->act == Y4_ACT_MISH &&
-                       chain->ntail == 1 && chain->fin && chain->fin_cstride % epc == 0 && chain->fin_coff % epc == 0 &&
-                       chain->tail[0].w && chain->tail[0].scale && chain->tail[0].shift && !chain->tail[0].src2 &&
-                       (chain->tail[0].cout == 32 || chain->tail[0].cout == 64),
-                   Y4_EINVAL, "conv2d: bad split-chain description");
-        k.ntail = 1; k.store_x = 1;
-        k.fin = (char*)chain->fin; k.fin_cstride = chain->fin_cstride; k.fin_coff = chain->fin_coff;
-        k.tail[0].w = (const char*)chain->tail[0].w; k.tail[0].scale = chain->tail[0].scale; k.tail[0].shift = chain->tail[0].shift;
-        k.tail[0].cout = chain->tail[0].cout;
-    } else if (chain && chain->ntail > 0) {
+    if (chain && chain->ntail > 0) {
         Y4_REQUIRE(d->dtype != Y4_F32 && d->cout == 64 && d->act == Y4_ACT_MISH && !d->upsample && !d->out_f32 && !d->out2 &&
                        chain->ntail <= 2 && chain->fin && chain->fin_cstride % epc == 0 && chain->fin_coff % epc == 0,
                    Y4_EINVAL, "conv2d: bad chain description");
@@ -560,8 +544,8 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
             k.tail[t].cout = ct.cout;
         }
     }
-    int tile = d->tile ? d->tile : pair ? (d->cout == 128 ? 20 : 19) : (split_chain ? 33 : k.ntail > 0 ? (d->cin % (128 / es) == 0 ? 3 : 4) : conv_pick_tile(d->dtype, k.M, d->cin, d->cout));
-    Y4_REQUIRE(k.ntail == 0 || chain_tile(tile, split_chain), Y4_EINVAL, "conv2d: tile id %d cannot head this chain", tile);
+    int tile = d->tile ? d->tile : pair ? (d->cout == 128 ? 20 : 19) : (k.ntail > 0 ? (d->cin % (128 / es) == 0 ? 3 : 4) : conv_pick_tile(d->dtype, k.M, d->cin, d->cout));
+    Y4_REQUIRE(k.ntail == 0 || chain_tile(tile), Y4_EINVAL, "conv2d: tile id %d cannot head this chain", tile);
     Y4_REQUIRE(!pair || (pair_tile(tile) && kTiles[tile - 1].bn == d->cout), Y4_EINVAL, "conv2d: tile id %d cannot head this LDS pair", tile);
     Y4_REQUIRE(tile >= 1 && tile <= kNumTiles, Y4_EINVAL, "conv2d: tile id %d out of range", tile);
     const TileCfg& tc = kTiles[tile - 1];

@@ -62,7 +62,6 @@ struct Layer {
 struct Chain {
     int head, tail[2];      // op indices (tail[1] = -1 for a 2-conv chain)
     bool store_x;           // the head's output has other consumers and is still written
-    bool split = false;     // head = a fused CSP pair (route | main-in), one tail reading the main-in half
     bool lds_pair = false;  // the tail runs from the head's tile kept in LDS (128/256 channels), not from registers
     bool enabled = true;    // y4_autotune turns a run off when its separate kernels measure faster
     int tile = 0;           // the head's tile when it runs chained (0 = heuristic); Op::tile stays the unfused choice
@@ -299,9 +298,8 @@ void find_chains(y4_ctx& c) {
             if (la.d.ksize == 1 && la.d.cin % 64 == 0 && la.d.cout == 64 && a.split == 64 && la.d.act == Y4_ACT_MISH && !a.has_res &&
                 lb.d.ksize == 1 && lb.d.cin == 64 && (lb.d.cout == 32 || lb.d.cout == 64) && lb.d.act == Y4_ACT_MISH && !b.has_res &&
                 !b.upsample && !b.out_f32 && same_view(b.in, a.out2) && !c.layers[b.conv].has_tail) {
-                Chain ch{i, {i + 1, -1}, true};
-                ch.split = true;
-                c.layers[b.conv].has_tail = true;
+                Chain ch{i, {i + 1, -1}, true};          // both halves of the pair have later readers
+                ch.lds_pair = true;
                 c.chains.push_back(ch);
             }
             continue;
