@@ -811,7 +811,40 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
                 if (ms >= 0.f && ms < best) { best = ms; best_tile = tile; }
             }
             ch.tile = best_tile;
-            ch.enabled = best_tile > 0 && best < separate;
+            ch.enabled = best_tile > 0;
+            if (!ch.enabled) continue;
+            // Final decision head to head, each variant as the executor would run it: the separate kernels in their real
+            // order (head, tail, tail -- not the same kernel back to back, which runs warmer than it ever does in a step)
+            // against the one fused launch, in alternating blocks and with several times the launches of a tile probe.
+            // Comparing `best` with the SUM of three per-tile minima instead is biased towards "separate" (a minimum of
+            // noisy samples is low, and three of them add up) and flipped the 8 % wins of the 76^2 pairs run to run.
+            (void)separate;
+            const int rounds = 4, per_round = reps > 3 ? reps : 3;
+            auto block = [&](bool fused) -> float {
+                if (hipEventRecord(e0, s) != hipSuccess) return -2.f;
+                for (int i = 0; i < per_round; ++i) {
+                    if (fused) {
+                        run_op(h, h->ops[ch.head], nullptr, images_of(ch.head), s, 0, true);
+                    } else {
+                        run_op(h, h->ops[ch.head], nullptr, images_of(ch.head), s, 0, false);
+                        run_op(h, h->ops[ch.tail[0]], nullptr, images_of(ch.tail[0]), s, 0, false);
+                        if (ch.tail[1] >= 0) run_op(h, h->ops[ch.tail[1]], nullptr, images_of(ch.tail[1]), s, 0, false);
+                    }
+                }
+                float ms = 0.f;
+                if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                    hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+                    return -2.f;
+                return ms;
+            };
+            float t_fused = 0.f, t_sep = 0.f;
+            block(true); block(false);                               // one untimed block each: both start equally warm
+            for (int r = 0; r < rounds && rc == Y4_OK; ++r) {
+                const float a = block(true), b = block(false);
+                if (a == -2.f || b == -2.f) { rc = Y4_EHIP; break; }
+                t_fused += a; t_sep += b;
+            }
+            ch.enabled = t_fused < t_sep;
         }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
