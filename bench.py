@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
-"""Headline benchmark: images/sec of the whole predict() hot path (forward + decode + NMS) at
+"""Headline benchmark: images/sec of the whole predict() hot path (forward + decode + NMS + results to the host) at
 608x608, 80 classes, batch 32 per GPU, bf16 storage / fp32 accumulate, synthetic data.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+      N > 1 without a torchrun environment: this process -- before it touches any GPU -- starts
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>`
+      as a child, relays its output (rank 0's JSON line) and exits with its return code.  Under torchrun
+      (RANK/LOCAL_RANK/WORLD_SIZE set) it is one rank of the job, one rank per GPU over RCCL.
 
-A step = one y4_predict over one batch of 32 images already resident in HBM (float32 NHWC in [0,1]; the
-PCIe-inclusive rate is noted in DESIGN.md, it is never `value`).  Timed region: barrier +
-torch.cuda.synchronize() on both sides, MAX over ranks, whole-job images / time.
-`roofline` is for the dominant kernel family (conv_igemm_kernel: convs 2..109, or 1..109 with --no-stem-fusion): algorithmic conv FLOPs of
-one step / its summed per-launch device time, measured with HIP events recorded on the launch stream
-inside the timed region (y4_timing_begin/end).  `cpu_baseline` times the oracle (a torch-CPU/NumPy
-restatement; the reference's tf.keras path cannot run here) on a bounded sample on rank 0 at N=1.
-With no flags the whole command (weight synthesis and packing, one-off tile / fusion autotune, 3 + 20 steps, ~9 s of
-CPU baseline) takes 16 s wall on an MI355X box (measured).
+A step = one y4_predict over one batch of 32 float32 NHWC images already resident in HBM (the PCIe-inclusive rate is
+noted in DESIGN.md, it is never `value`) followed by ONE 77 KB device->host copy of the four NMS outputs (+ kept
+indices), as SURVEY.md section 8(d) defines the metric.  Timing: W untimed warm-up steps, then R (--blocks, default 5)
+blocks of EXACTLY K steps, each block bracketed by barrier + torch.cuda.synchronize() on both sides and reduced with MAX
+over ranks; `ms_per_step` / `value` are the MEDIAN block (one 0.13 s sample on a pool whose boxes differ by +-3 % was too
+noisy), every block is listed under `blocks_ms_per_step`.
+`roofline` is for the dominant kernel family (the conv kernels: convs 2..109 with the stem fusion, else 1..109):
+algorithmic conv FLOPs of one step / its summed device time, measured with HIP events recorded on the launch stream
+inside the timed blocks (y4_timing_begin/end).  `cpu_baseline` times the oracle (a torch-CPU/NumPy restatement; the
+reference's tf.keras path cannot run here) on a bounded sample on rank 0 at N=1.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -27,11 +34,11 @@ for p in (os.path.join(ROOT, "yolo-v4-tf.keras_amd"), ROOT):
         sys.path.insert(0, p)
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+METRIC = "images/sec end-to-end predict() at 608x608 batch 32; conv MFMA %peak"
 
 
 def cpu_baseline(size, ncls, ws, cfg, sample_n=8, runs=3):
     """Oracle (kind 'port') on the host cores: forward + decode + NMS of `sample_n` images."""
-    import numpy as np
     import torch
     from yolo4hip import weights as W
     from oracle import forward as OF, decode_nms as OD
@@ -54,27 +61,53 @@ def cpu_baseline(size, ncls, ws, cfg, sample_n=8, runs=3):
                       f"+ NumPy decode/NMS (oracle/), after 1 warm-up run; {dt:.1f} s of CPU work"}
 
 
-def measured_traffic(args, fused_stem, chained, launches):
-    """HBM bytes per conv_igemm launch from the committed PMC passes (profiles/r01/hbm_traffic_v3.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes),
-    or None when this run's configuration is not the profiled one.  Counters cannot be read from inside the process."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "hbm_traffic_v3.json")
-    try:
-        prof = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    want = {"size": args.size, "classes": args.classes, "batch": args.batch, "dtype": args.dtype,
-            "stem_fusion": bool(fused_stem), "chain_fusion": bool(chained)}
-    if prof.get("config") != want or launches <= 0:
-        return None
-    return round(prof["conv_igemm_hbm_bytes_per_step"] / launches)
+def committed_traffic(args, fused_stem, chained, staged):
+    """HBM bytes per STEP of the conv kernel family from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes), or (None, reason) when this
+    run's configuration is not the profiled one.  Counters cannot be read from inside the process: the figure is NOT
+    measured by this run, `traffic_source` says where it comes from."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, "hbm_traffic.json" if rnd != "r01" else "hbm_traffic_v3.json")
+        try:
+            prof = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        want = {"size": args.size, "classes": args.classes, "batch": args.batch, "dtype": args.dtype,
+                "stem_fusion": bool(fused_stem), "chain_fusion": bool(chained)}
+        have = dict(prof.get("config", {}))
+        if "stage_fusion" in have:
+            want["stage_fusion"] = bool(staged)
+        elif staged:
+            continue                                   # profiled before the stage fusion existed
+        if have != want:
+            continue
+        return int(prof["conv_igemm_hbm_bytes_per_step"]), \
+            f"profiles/{rnd}/{os.path.basename(path)} (committed rocprofv3 --pmc passes of this command; not measured by this run)"
+    return None, "no committed PMC pass matches this configuration"
 
 
-def main():
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n_gpus, argv):
+    """Parent of an N > 1 run started without torchrun.  Nothing here touches the GPU (no torch import even): the ranks
+    are fresh child processes, never an exec of a process that initialised HIP."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; the median block is reported")
     ap.add_argument("--size", type=int, default=608)
     ap.add_argument("--classes", type=int, default=80)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
@@ -88,10 +121,55 @@ def main():
     ap.add_argument("--sub-last-conv", type=int, default=16)
     ap.add_argument("--no-stem-fusion", action="store_true", help="run convs 0 and 1 as two kernels (c0 through HBM)")
     ap.add_argument("--no-chain-fusion", action="store_true", help="run the 3x3+Add -> 1x1 -> 1x1 runs as separate kernels")
+    ap.add_argument("--no-stage-fusion", action="store_true", help="run the 304^2 CSP stage (convs 2..7) as separate kernels")
     ap.add_argument("--per-op", action="store_true", help="also print the per-op time table to stderr")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / protocol self-test on CPU (gloo, no engine, no GPU work): the line says so")
+    return ap.parse_args(argv)
+
+
+def dry_run(args):
+    """The multi-process protocol of the bench without an engine (tests/test_bench_launcher.py): process group, shard
+    ranges, barrier-bracketed blocks, MAX over ranks, one JSON line from rank 0."""
+    import torch.distributed as dist
+    from yolo4hip import dist as D
+    rank, local_rank, world = D.init_process_group(backend="gloo")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    lo, hi = D.shard_range(args.batch * world, rank, world)
+    blocks = []
+    for _ in range(args.blocks):
+        D.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(0.001)
+        D.barrier()
+        blocks.append(D.max_over_ranks(time.perf_counter() - t0))
+    if rank == 0:
+        dt = statistics.median(blocks)
+        print(json.dumps({"metric": METRIC + " [DRY RUN: no GPU work]", "value": round(args.batch * world * args.steps / dt, 2),
+                          "unit": "images/sec", "n_gpus": dist.get_world_size() if dist.is_initialized() else 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+                          "data": "dry-run (no GPU work)", "config": {"workload": "launcher self-test", "shard": [lo, hi]}}),
+              flush=True)
+    D.barrier()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, argv))
+    if args.batch < 1 or args.steps < 1 or args.blocks < 1 or args.gpus < 1:
+        raise SystemExit("bench.py: --batch, --steps, --blocks and --gpus must be >= 1")
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
+    import torch.distributed as dist
     from yolo4hip import dist as D, weights as W
     from yolo4hip.config import make_config
     from yolo4hip.engine import Engine
@@ -99,7 +177,7 @@ def main():
 
     rank, local_rank, world = D.init_process_group()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     cfg = make_config(args.size)
     plan = build_plan(args.size, args.classes)
@@ -113,76 +191,94 @@ def main():
     D.load_weights_distributed(eng, make_flat, src=0)          # rank 0 packs, RCCL broadcast of the packed blob
     lo, hi = D.shard_range(args.batch * world, rank, world)    # this rank's slice of the global batch
     imgs = torch.from_numpy(W.synth_images(hi - lo, args.size, seed=0, first_index=lo)).to(eng.device)
-    outs = eng.alloc_outputs(hi - lo)
+    flat, outs = eng.alloc_outputs_flat(hi - lo)               # five outputs in one block: ONE D2H copy per step
+    host = torch.empty(flat.numel(), dtype=torch.int32).pin_memory()
     if args.subbatch > 0:
         eng.set_subbatch(args.subbatch, args.sub_last_conv)
     fused_stem = args.dtype != "f32" and args.size <= 640 and not args.no_stem_fusion
     if fused_stem:
-        eng.set_stem_fusion(True)          # convs 0+1 in one kernel; conv 1 then leaves the conv_igemm family below
+        eng.set_stem_fusion(True)          # convs 0+1 in one kernel; conv 1 then leaves the conv family below
     first_conv = 2 if fused_stem else 1
     chained = 0
     if args.dtype != "f32" and not args.no_chain_fusion:
-        chained = eng.set_chain_fusion(True)      # 25 runs of 2-3 convs (CSP stages) -> one conv_igemm launch each
+        chained = eng.set_chain_fusion(True)      # runs of 2-3 convs (CSP stages) -> one conv_igemm launch each
+    staged = False
+    if args.dtype != "f32" and not args.no_stage_fusion and hasattr(eng, "set_stage_fusion"):
+        staged = bool(eng.set_stage_fusion(True))  # convs 2..7 (304^2 CSP stage) as one spatially tiled kernel
     if args.load_tiles:
-        tiles = json.load(open(args.load_tiles))["tiles"]
+        saved = json.load(open(args.load_tiles))
+        tiles = saved["tiles"]
         eng.set_tiles(tiles)
+        if staged and "stage_fusion" in saved:
+            staged = bool(eng.set_stage_fusion(saved["stage_fusion"]))
     elif not args.no_autotune:
         eng.predict_device(imgs, outs)                        # real activations in the workspace
-        tiles = eng.autotune(hi - lo, reps=args.tune_reps)                         # untimed, one-off: fastest tile per layer (bit-identical results)
+        tiles = eng.autotune(hi - lo, reps=args.tune_reps)    # untimed, one-off: fastest tile / fusion per layer (bit-identical results)
+        if staged:
+            staged = bool(eng.stage_fusion_active())          # the tuner may have turned the stage kernel off
     else:
         tiles = None
     if args.save_tiles and rank == 0 and tiles:
-        json.dump({"size": args.size, "classes": args.classes, "batch": args.batch, "dtype": args.dtype, "tiles": tiles},
-                  open(args.save_tiles, "w"))
+        json.dump({"size": args.size, "classes": args.classes, "batch": args.batch, "dtype": args.dtype, "tiles": tiles,
+                   "stage_fusion": bool(staged)}, open(args.save_tiles, "w"))
+
+    def step():
+        eng.predict_device(imgs, outs)
+        host.copy_(flat, non_blocking=True)                   # boxes, scores, classes, valid (+ kept) -> host, 77 KB
 
     for _ in range(args.warmup):
-        eng.predict_device(imgs, outs)
+        step()
     torch.cuda.synchronize()
-    D.barrier()
-    torch.cuda.synchronize()
-    eng.timing_begin(args.steps, coarse=not args.per_op)    # 7 events per step (conv runs timed as a whole) unless --per-op
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.predict_device(imgs, outs)
-    torch.cuda.synchronize()
-    D.barrier()
-    torch.cuda.synchronize()
-    dt = D.max_over_ranks(time.perf_counter() - t0)
+    eng.timing_begin(args.steps * args.blocks, coarse=not args.per_op)    # 7 events per step unless --per-op
+    blocks = []
+    for _ in range(args.blocks):
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+        blocks.append(D.max_over_ranks(time.perf_counter() - t0))
     ops, nrec = eng.timing_end()
 
     if rank == 0:
+        dt = statistics.median(blocks)
         n_img = args.batch * world * args.steps
-        conv_ms = sum(ms for name, ms in ops if name.startswith("c") and name != "c0")
+        is_conv = lambda name: name.startswith("c") and name != "c0"
+        conv_ms = sum(ms for name, ms in ops if is_conv(name))
         conv_flops = sum(c.flops_per_image for c in plan.convs[first_conv:]) * (hi - lo)
-        launches = sum(1 for name, _ in ops if name.startswith("c") and name != "c0")   # fused CSP pairs count once
-        other = {name: ms for name, ms in ops if not name.startswith("c") or name == "c0"}
+        other = {name: ms for name, ms in ops if not is_conv(name)}
         total_ms = sum(ms for _, ms in ops)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.dtype]
-        # tails that run inside their head's kernel: heads are reported as -tile by the autotuner / tile file
-        tails_of = {2: 1, 5: 2, 8: 1, 12: 1, 14: 2, 17: 1}
-        tails_of.update({h: 1 for h in list(range(21, 36, 2)) + list(range(42, 57, 2)) + [88, 90, 92]})   # LDS pairs
-        fused_tails = sum(n_t for head, n_t in tails_of.items() if chained and (tiles is None or tiles[head] <= 0))
-        conv_launches = launches - (first_conv - 1) - fused_tails
+        conv_launches = eng.conv_launches_per_step()
+        traffic, traffic_source = committed_traffic(args, fused_stem, chained, staged)
         line = {
-            "metric": "images/sec end-to-end predict() at 608x608 batch 32; conv MFMA %peak",
-            "value": round(n_img / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC,
+            "value": round(n_img / dt, 2), "unit": "images/sec",
+            "n_gpus": dist.get_world_size() if dist.is_initialized() else 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"yolov4 predict(): {args.size}x{args.size}x3 float32 images resident in HBM -> "
                                    f"CSPDarknet53+SPP+PANet forward ({plan.flops_per_image / 1e9:.3f} GFLOP/image) "
-                                   f"-> 3-scale decode ({plan.num_boxes} boxes) -> class-aware NMS (100/image); "
-                                   f"{args.classes} classes, {args.dtype} storage, fp32 accumulate, "
-                                   f"seeded synthetic weights",
+                                   f"-> 3-scale decode ({plan.num_boxes} boxes) -> class-aware NMS (100/image) -> "
+                                   f"4 NMS outputs on the host; {args.classes} classes, {args.dtype} storage, "
+                                   f"fp32 accumulate, seeded synthetic weights",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "sharding": f"batch split over {world} rank(s), no data-path collective"},
+            "blocks_ms_per_step": [round(b / args.steps * 1e3, 4) for b in blocks],
+            "timing": f"median of {args.blocks} blocks of {args.steps} steps, each barrier+synchronize bracketed, max over ranks",
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
-                         "traffic": measured_traffic(args, fused_stem, chained, conv_launches),
-                         "kernel": "conv_igemm_kernel (convs %d..109, %d launches/step)" % (first_conv, conv_launches),
+                         "traffic": traffic, "traffic_unit": "HBM bytes per step (all launches of the family)",
+                         "traffic_source": traffic_source,
+                         "kernel": "conv kernel family (convs %d..109, %d launches/step%s)" %
+                                   (first_conv, conv_launches, ", convs 2..7 in csp_stage_kernel" if staged else ""),
                          "flops_per_step": conv_flops, "kernel_ms_per_step": round(conv_ms, 4),
                          "timed_steps": nrec},
-            "breakdown_ms_per_step": {"conv_igemm": round(conv_ms, 4), ("stem_c0+c1_fused" if fused_stem else "stem_c0"): round(other.get("c0", 0.0), 4),
+            "breakdown_ms_per_step": {"conv_family": round(conv_ms, 4), ("stem_c0+c1_fused" if fused_stem else "stem_c0"): round(other.get("c0", 0.0), 4),
                                       "spp": round(other.get("spp", 0.0), 4),
                                       "decode": round(other.get("decode", 0.0), 4),
                                       "nms": round(other.get("nms", 0.0), 4), "sum_of_ops": round(total_ms, 4),
@@ -199,7 +295,6 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.size, args.classes, ws, cfg)
         print(json.dumps(line), flush=True)
     D.barrier()
-    import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 

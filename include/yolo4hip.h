@@ -157,6 +157,11 @@ int y4_set_stem_fusion(y4_handle h, int on);
  * accepts the same encoding; > 0 there means separate kernels, 0 fused with the built-in tile). */
 int y4_set_chain_fusion(y4_handle h, int on);
 
+/* Kernel launches of one y4_predict under the current fusion / tile settings (whole batch, no sub-batching):
+ * `conv_family` = launches of the conv kernels other than the stem (what bench.py's roofline is quoted on),
+ * `total` = all launches including stem, SPP, decode and NMS. */
+int y4_launch_counts(y4_handle h, int32_t* conv_family, int32_t* total);
+
 /* Live per-op timing of the calls in between: while a session is open, each y4_predict (up to max_steps of
  * them) records a HIP event on its stream after every op, without synchronising.  y4_timing_end
  * synchronises the stream and returns the mean device time per op in ms ('c1'.., 'spp', 'decode', 'nms').

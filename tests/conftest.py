@@ -1,6 +1,8 @@
 import os
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "yolo-v4-tf.keras_amd"), ROOT, os.path.dirname(os.path.abspath(__file__))):
     if p not in sys.path:
@@ -9,3 +11,29 @@ for p in (os.path.join(ROOT, "yolo-v4-tf.keras_amd"), ROOT, os.path.dirname(os.p
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_unavailable_reason():
+    """None when the `-m gpu` tests can run here, else why not (they are then SKIPPED, never faked on a CPU path)."""
+    so = os.path.join(ROOT, "yolo-v4-tf.keras_amd", "yolo4hip", "libyolo4hip.so")
+    if not os.path.exists(so):
+        return f"{so} is not built (run __graft_entry__.build())"
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return "no ROCm GPU visible (torch.cuda.is_available() is False)"
+    except Exception as e:                       # pragma: no cover
+        return f"torch unavailable: {e}"
+    return None
+
+
+def pytest_collection_modifyitems(config, items):
+    gpu_items = [it for it in items if it.get_closest_marker("gpu")]
+    if not gpu_items:
+        return
+    reason = _gpu_unavailable_reason()
+    if reason is None:
+        return
+    skip = pytest.mark.skip(reason=reason)
+    for it in gpu_items:
+        it.add_marker(skip)

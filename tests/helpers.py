@@ -86,3 +86,42 @@ def make_conv_weights(rng, cout, cin, k, bn=True):
                       0.2 * rng.standard_normal(cout), 0.5 + rng.random(cout)]).astype(np.float32)
         return ConvWeights(w=w, bn=b)
     return ConvWeights(w=w, bias=(rng.standard_normal(cout) * 0.5).astype(np.float32))
+
+
+def randomize_bn(ws, seed):
+    """Function-preserving re-parametrisation of a weight set with NON-TRIVIAL BatchNorm statistics: every BN
+    conv gets random mean (+-0.5), var (0.3..3) and gamma (0.5..1.5); the kernel and beta are adjusted so that
+    the layer computes the same function in exact arithmetic (the synthetic net stays well conditioned), while
+    `scale = gamma*rsqrt(var+eps)`, `shift = beta - mean*scale` (reference utils.py:28-31, custom_layers.py:26)
+    now depend on all four rows.  A sign or row-order slip in the device-side fold then shows up at O(1)."""
+    from yolo4hip.weights import BN_EPS, ConvWeights
+    rng = np.random.default_rng([seed, 0xB17])
+    out = []
+    for cw in ws:
+        if cw.bn is None:
+            out.append(cw)
+            continue
+        beta, gamma, mean, var = cw.bn.astype(np.float64)
+        cout = beta.size
+        scale0 = gamma / np.sqrt(var + BN_EPS)
+        shift0 = beta - mean * scale0
+        g2 = rng.uniform(0.5, 1.5, cout)
+        v2 = rng.uniform(0.3, 3.0, cout)
+        m2 = rng.uniform(-0.5, 0.5, cout)
+        scale2 = g2 / np.sqrt(v2 + BN_EPS)
+        w2 = (cw.w.astype(np.float64) * (scale0 / scale2)[:, None, None, None]).astype(np.float32)
+        beta2 = shift0 + m2 * scale2
+        bn2 = np.stack([beta2, g2, m2, v2]).astype(np.float32)
+        out.append(ConvWeights(w=w2, bn=bn2))
+    return out
+
+
+def detection_agreement(kept, classes, scores, boxes, valid, ri, rc, rs, rb, rv):
+    """Per-image agreement of two NMS results matched by (box index, class): fraction of the reference's
+    detections also present, max |score delta| and max |box delta| over the matched ones."""
+    got = {(int(kept[j]), int(classes[j])): j for j in range(int(valid))}
+    ref = {(int(ri[j]), int(rc[j])): j for j in range(int(rv))}
+    common = set(got) & set(ref)
+    ds = max((abs(float(scores[got[k]]) - float(rs[ref[k]])) for k in common), default=0.0)
+    db = max((float(np.abs(boxes[got[k]] - rb[ref[k]]).max()) for k in common), default=0.0)
+    return (len(common) / max(len(ref), 1)), ds, db

@@ -37,6 +37,14 @@ def _worker(rank, world, port, ret):
     g = D.gather_results([res, valid], n_total)
     full = W.synth_images(n_total, 16, seed=3).reshape(n_total, -1)[:, :4]
     ok_gather = np.array_equal(g[0], full) and np.array_equal(g[1], np.arange(n_total, dtype=np.int32))
+    # 2b. a batch that does not divide by the world size: shards of 3 and 2 images (the short shard is NOT the last
+    #     rows of the padded gather, so stripping must be per rank)
+    n_odd = 5
+    lo2, hi2 = D.shard_range(n_odd, rank, world)
+    g2 = D.gather_results([torch.arange(lo2, hi2, dtype=torch.int32),
+                           torch.arange(lo2, hi2, dtype=torch.float32).view(-1, 1).repeat(1, 3)], n_odd)
+    ok_gather = ok_gather and np.array_equal(g2[0], np.arange(n_odd, dtype=np.int32)) and \
+        np.array_equal(g2[1], np.arange(n_odd, dtype=np.float32).reshape(-1, 1).repeat(3, axis=1))
     mx = D.max_over_ranks(10.0 + rank)
     D.barrier()
     ret[rank] = (ok_bcast, ok_gather, mx)

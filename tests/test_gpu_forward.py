@@ -120,8 +120,8 @@ def test_fp32_forward_and_nms_parity(size, ncls, n):
     eng.close()
 
 
-@pytest.mark.parametrize("dtype,tol", [("bf16", 0.35), ("f16", 0.06)])
-def test_16bit_forward_close_to_fp32_oracle(dtype, tol):
+@pytest.mark.parametrize("dtype,tol,min_common", [("bf16", 0.35, 0.6), ("f16", 0.06, 0.6)])
+def test_16bit_forward_close_to_fp32_oracle(dtype, tol, min_common):
     """16-bit storage: heads stay close to the fp32 oracle (bound = observed error budget of 110 layers of
     8-bit/11-bit mantissa rounding on O(1) logits with std ~1.3), and most detections coincide."""
     from oracle import forward as OF, decode_nms as OD
@@ -129,15 +129,26 @@ def test_16bit_forward_close_to_fp32_oracle(dtype, tol):
     cfg, plan, ws, imgs, eng = _setup(size, ncls, n, dtype)
     ref_heads = OF.yolo_model_forward(imgs, ws, ncls)
     heads = eng.forward_heads(imgs)
+    measured = []
     for a, b in zip(heads, ref_heads):
         err = np.abs(a - b)
         assert np.isfinite(a).all()
+        measured.append((float(err.mean()), float(np.quantile(err, 0.999))))
         assert err.mean() < tol / 4 and np.quantile(err, 0.999) < tol, (err.mean(), err.max())
     boxes, scores, classes, valid, kept = eng.predict(imgs, with_indices=True)
     rb, rs, rc, rv, ri = OD.inference_from_heads(ref_heads, ncls, cfg["anchors"], cfg["xyscale"], size)
+    fracs = []
     for b in range(n):
-        common = len(set(kept[b, :valid[b]].tolist()) & set(ri[b, :rv[b]].tolist()))
-        assert common >= 0.6 * rv[b], (common, rv[b])
+        common = len(set(zip(kept[b, :valid[b]].tolist(), classes[b, :valid[b]].tolist())) &
+                     set(zip(ri[b, :rv[b]].tolist(), rc[b, :rv[b]].tolist())))
+        fracs.append(common / max(int(rv[b]), 1))
+        assert common >= min_common * rv[b], (common, rv[b])
+    try:
+        import json, os
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_measured.jsonl"), "a") as f:
+            f.write(json.dumps({"test": f"416_3_{dtype}_b2", "head_err_mean_q999": measured, "matched": fracs}) + "\n")
+    except OSError:
+        pass
     eng.close()
 
 

@@ -1,0 +1,175 @@
+"""GPU parity at BASELINE.json's real configurations against the oracle, and of the device-side BatchNorm fold.
+
+  * config 3 (608x608, 80 classes, bf16, fusions + autotune on): head logits and detections of 4 images of the batch vs
+    the fp32 oracle, with the error budget STATED here (and recorded in DESIGN.md section 2);
+  * config 5 (416x416, 3 classes, fp16) at its real batch of 64: size-independent properties over the whole batch and
+    4 images vs the oracle;
+  * `y4_pack_weights` -> fold_bn_kernel (csrc/misc_kernels.hip) with random BN mean / var / gamma against the oracle
+    (reference utils.py:28-31 row order [beta, gamma, mean, var]; custom_layers.py:26 eps 1e-3).
+The measured numbers of each run are appended to gpurun_out/parity_measured.jsonl (scratch) for DESIGN.md.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, detection_agreement, randomize_bn
+
+pytestmark = pytest.mark.gpu
+
+
+def _record(tag, payload):
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_measured.jsonl"), "a") as f:
+            f.write(json.dumps({"test": tag, **payload}) + "\n")
+    except OSError:
+        pass
+
+
+def _engine(size, ncls, n, dtype, ws):
+    from yolo4hip import weights as W
+    from yolo4hip.config import make_config
+    from yolo4hip.engine import Engine
+    cfg = make_config(size)
+    eng = Engine(ncls, cfg, max_batch=n, dtype=dtype)
+    eng.load_weight_blob(W.flatten(ws))
+    return cfg, eng
+
+
+def _head_errors(heads, ref_heads, rows):
+    out = []
+    for a, b in zip(heads, ref_heads):
+        err = np.abs(a[rows] - b)
+        assert np.isfinite(a).all()
+        out.append((float(err.mean()), float(np.quantile(err, 0.999)), float(err.max())))
+    return out
+
+
+# Error budget of 16-bit STORAGE through 110 layers (fp32 accumulate, fp32 BN/activation; every activation tensor rounded
+# to 8 (bf16) / 11 (fp16) mantissa bits), on raw head logits of std ~1.3.  Bounds = measured on MI355X + ~40 % margin
+# (the measured values are in DESIGN.md section 2); identical kept indices are NOT claimed at 16-bit precision.
+BUDGET = {
+    #        mean |err|, 99.9 % quantile, min matched fraction, max score delta on matched detections
+    "bf16": (0.035, 0.22, 0.80, 0.08),
+    "f16": (0.0045, 0.03, 0.95, 0.012),
+}
+
+
+def test_headline_config_bf16_vs_oracle():
+    """BASELINE.json config 3: 608x608, 80 classes, bf16, batch 32, stem + chain + stage fusions and autotune on -- the
+    exact schedule bench.py times -- against oracle.forward (fp32) on 4 images of the batch (indices 0, 9, 18, 31)."""
+    import torch
+    from oracle import forward as OF, decode_nms as OD
+    from yolo4hip import weights as W
+    from yolo4hip.plan import build_plan
+    size, ncls, n, dtype = 608, 80, 32, "bf16"
+    ws = W.synth_weights(build_plan(size, ncls), seed=0)
+    imgs = W.synth_images(n, size, seed=0)
+    cfg, eng = _engine(size, ncls, n, dtype, ws)
+    eng.set_stem_fusion(True)
+    eng.set_chain_fusion(True)
+    dev = torch.from_numpy(imgs).to(eng.device)
+    eng.predict_device(dev)
+    eng.autotune(n, reps=2)
+    outs = [o.cpu().numpy() for o in eng.predict_device(dev)]
+    heads = [h.cpu().numpy() for h in eng.heads_device(n)]
+    rows = [0, 9, 18, 31]
+    ref_heads = OF.yolo_model_forward(imgs[rows], ws, ncls)
+    errs = _head_errors(heads, ref_heads, rows)
+    rb, rs, rc, rv, ri = OD.inference_from_heads(ref_heads, ncls, cfg["anchors"], cfg["xyscale"], size)
+    boxes, scores, classes, valid, kept = outs
+    agree = [detection_agreement(kept[r], classes[r], scores[r], boxes[r], valid[r], ri[j], rc[j], rs[j], rb[j], rv[j])
+             for j, r in enumerate(rows)]
+    _record("headline_608_80_bf16_b32", {"head_err_mean_q999_max": errs, "agreement_frac_dscore_dbox": agree,
+                                         "valid": [int(valid[r]) for r in rows], "ref_valid": [int(v) for v in rv]})
+    mean_b, q_b, frac_b, ds_b = BUDGET[dtype]
+    for i, (m, q, _) in enumerate(errs):
+        assert m < mean_b and q < q_b, f"head {i}: mean {m:.4f} q99.9 {q:.4f}"
+    for j, (frac, ds, db) in enumerate(agree):
+        assert frac >= frac_b and ds < ds_b, f"image {rows[j]}: matched {frac:.3f}, score delta {ds:.4f}, box delta {db:.4f}"
+    assert sum(int(v) for v in rv) > 40, "the synthetic heads must give NMS real work"
+    eng.close()
+
+
+def test_config5_416_b64_f16_real_batch():
+    """BASELINE.json config 5 at its real size: 416x416, 3 classes (bccd), fp16, batch 64.  Whole batch: the fused +
+    autotuned schedule equals the plain one bit for bit, the step is deterministic, image i of the batch equals image i
+    alone; 4 images vs the fp32 oracle within the fp16 budget."""
+    import torch
+    from oracle import forward as OF, decode_nms as OD
+    from yolo4hip import weights as W
+    from yolo4hip.plan import build_plan
+    size, ncls, n, dtype = 416, 3, 64, "f16"
+    ws = W.synth_weights(build_plan(size, ncls), seed=0)
+    imgs = W.synth_images(n, size, seed=11)
+    cfg, eng = _engine(size, ncls, n, dtype, ws)
+    dev = torch.from_numpy(imgs).to(eng.device)
+    plain = [o.cpu().numpy() for o in eng.predict_device(dev)]
+    eng.set_stem_fusion(True)
+    eng.set_chain_fusion(True)
+    eng.autotune(n, reps=1)
+    run1 = [o.cpu().numpy() for o in eng.predict_device(dev)]
+    heads = [h.cpu().numpy() for h in eng.heads_device(n)]
+    run2 = [o.cpu().numpy() for o in eng.predict_device(dev)]
+    for a, b, c in zip(run1, run2, plain):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    boxes, scores, classes, valid, kept = run1
+    assert valid.sum() > 64 and valid.max() <= 100
+    for i in (0, 21, 63):
+        one = [o.cpu().numpy() for o in eng.predict_device(dev[i:i + 1])]
+        for a, b in zip(run1, one):
+            assert np.array_equal(a[i:i + 1], b), i
+    rows = [0, 13, 40, 63]
+    ref_heads = OF.yolo_model_forward(imgs[rows], ws, ncls)
+    errs = _head_errors(heads, ref_heads, rows)
+    rb, rs, rc, rv, ri = OD.inference_from_heads(ref_heads, ncls, cfg["anchors"], cfg["xyscale"], size)
+    agree = [detection_agreement(kept[r], classes[r], scores[r], boxes[r], valid[r], ri[j], rc[j], rs[j], rb[j], rv[j])
+             for j, r in enumerate(rows)]
+    _record("config5_416_3_f16_b64", {"head_err_mean_q999_max": errs, "agreement_frac_dscore_dbox": agree,
+                                      "valid": [int(valid[r]) for r in rows], "ref_valid": [int(v) for v in rv]})
+    mean_b, q_b, frac_b, ds_b = BUDGET[dtype]
+    for i, (m, q, _) in enumerate(errs):
+        assert m < mean_b and q < q_b, f"head {i}: mean {m:.4f} q99.9 {q:.4f}"
+    for j, (frac, ds, db) in enumerate(agree):
+        assert frac >= frac_b and ds < ds_b, f"image {rows[j]}: matched {frac:.3f}, score delta {ds:.4f}"
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_bn_fold_with_real_statistics(dtype):
+    """fold_bn_kernel through y4_pack_weights with random BN mean (+-0.5), var (0.3..3), gamma (0.5..1.5) on all 107 BN
+    layers (helpers.randomize_bn: function-preserving, so the net stays well conditioned) against the oracle, which
+    applies gamma*rsqrt(var+eps), beta-mean*scale itself.  Power check: the oracle with `mean` negated is far away."""
+    import torch
+    from oracle import forward as OF
+    from yolo4hip import weights as W
+    from yolo4hip.plan import build_plan
+    size, ncls, n = 160, 3, 2
+    plan = build_plan(size, ncls)
+    ws = randomize_bn(W.synth_weights(plan, seed=2), seed=2)
+    assert max(float(np.abs(cw.bn[2]).max()) for cw in ws if cw.bn is not None) > 0.45
+    imgs = W.synth_images(n, size, seed=2)
+    cfg, eng = _engine(size, ncls, n, dtype, ws)
+    heads = eng.forward_heads(imgs)
+    ref = OF.yolo_model_forward(imgs, ws, ncls)
+    if dtype == "f32":
+        ref64 = OF.yolo_model_forward(imgs, ws, ncls, dtype=torch.float64)
+        for i, (a, b, c) in enumerate(zip(heads, ref, ref64)):
+            e_gpu, e_cpu = np.abs(a - c).max(), np.abs(b - c).max()
+            assert e_gpu <= 2 * e_cpu + 1e-5, f"head {i}: HIP err vs fp64 {e_gpu:.3e}, oracle fp32 err {e_cpu:.3e}"
+            assert np.abs(a - b).max() < 3e-3, f"head {i}: {np.abs(a - b).max():.3e}"
+    else:
+        for i, (m, q, _) in enumerate(_head_errors(heads, ref, slice(None))):
+            assert m < BUDGET["bf16"][0] and q < BUDGET["bf16"][1], f"head {i}: mean {m:.4f} q99.9 {q:.4f}"
+    flipped = []
+    for cw in ws:
+        if cw.bn is None:
+            flipped.append(cw)
+        else:
+            bn = cw.bn.copy(); bn[2] = -bn[2]
+            flipped.append(type(cw)(w=cw.w, bn=bn))
+    wrong = OF.yolo_model_forward(imgs, flipped, ncls)
+    assert max(float(np.abs(a - b).max()) for a, b in zip(heads, wrong)) > 0.5, "test has no power against a mean sign slip"
+    eng.close()

@@ -1,19 +1,4 @@
 #!/bin/bash
-# Builds libyolo4hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU).
+# Builds libyolo4hip.so in-tree for gfx950 (see build.py: content-hash incremental build; Y4_CLEAN=1 forces a clean one).
 set -e
-cd "$(dirname "$0")"
-OUT=../yolo4hip/libyolo4hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
-mkdir -p build
-pids=()
-for f in conv_igemm misc_kernels stem_down decode_nms runtime; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ conv_common.h -nt build/$f.o ] || [ conv_chain.h -nt build/$f.o ] || [ stem_common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ ../../include/yolo4hip.h -nt build/$f.o ]; then
-    hipcc $FLAGS -c $f.hip -o build/$f.o &
-    pids+=($!)
-  fi
-done
-for p in "${pids[@]}"; do wait $p || { echo "compile failed"; exit 1; }; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/conv_igemm.o build/misc_kernels.o build/stem_down.o build/decode_nms.o build/runtime.o
-# every kernel must have its host stub (a target builtin inside a template can silently drop it)
-if nm -D --undefined-only $OUT | grep -q "_ZN2y4"; then echo "error: undefined y4 symbols in $OUT"; nm -D --undefined-only $OUT | grep "_ZN2y4" | head -3; exit 1; fi
-echo "built $OUT"
+exec python3 "$(dirname "$0")/build.py" "$@"

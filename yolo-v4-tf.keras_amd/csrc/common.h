@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/yolo4hip.h"
@@ -27,6 +28,21 @@ void set_error(const char* fmt, ...);
             return (code);                \
         }                                 \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: one flag per (call site, device
+// ordinal), so a second engine on another GPU of the same process -- or a second thread -- opts in too.  Setting the
+// attribute twice is harmless, so a lost race costs one redundant call.
+struct PerDeviceOnce {
+    std::atomic<uint64_t> done{0};
+    // returns the bit of the current device if the action is still due there, else 0
+    uint64_t due() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 1;
+        const uint64_t bit = 1ull << (dev & 63);
+        return (done.load(std::memory_order_acquire) & bit) ? 0 : bit;
+    }
+    void mark(uint64_t bit) { done.fetch_or(bit, std::memory_order_release); }
+};
 
 inline int elem_size(int dtype) { return dtype == Y4_F32 ? 4 : 2; }
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

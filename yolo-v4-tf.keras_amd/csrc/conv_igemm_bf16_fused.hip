@@ -1,0 +1,7 @@
+// conv_igemm_bf16_fused.hip -- instantiates conv_igemm_kernel's fused launches for Y4_BF16 (split per dtype so the library builds in
+// parallel; the kernel itself is conv_igemm_kernel.h).
+#include "conv_igemm_kernel.h"
+
+namespace y4 {
+int conv_launch_bf16_fused(int tile, const ConvK& k, hipStream_t s) { return launch_fused<Y4_BF16>(tile, k, s); }
+}  // namespace y4

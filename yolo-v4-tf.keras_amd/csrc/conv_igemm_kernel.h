@@ -1,0 +1,414 @@
+// conv_igemm_kernel.h -- the reference's conv() unit (custom_layers.py:5-31: Conv2D -> BatchNormalization ->
+// Mish/LeakyReLU) as ONE im2col-free implicit-GEMM MFMA kernel for gfx950, with the graph's glue ops
+// folded into its epilogue: residual Add (custom_layers.py:44), Concatenate (:68,:149,... -> a channel
+// slice store), UpSampling2D (:147,:159 -> 2x2 replicated store).
+//
+// GEMM view (NHWC activations):  D[ch][px] = sum_k Wt[ch][k] * X[px][k],  k = (ky*kw + kx)*Cin + ci
+//   X rows are gathered on the fly: for K-tile (tap, c0) row px is the BK contiguous channels
+//   in[n, ho*s+ky-pad, wo*s+kx-pad, c0:c0+BK]  (zero page when the tap falls in the padding),
+//   copied HBM/L2 -> LDS with global_load_lds (16 B per lane, no VGPR round trip).
+//   Weights are pre-packed [cout_pad][kh][kw][cin] so their K-tile rows are contiguous too.
+// The weight fragment is the MFMA *A* operand and the pixel fragment the *B* operand, so the accumulator
+// layout is D[row = channel][col = pixel]: every lane ends up holding runs of 8 CONSECUTIVE channels of one
+// pixel (the channel <-> MFMA-row assignment is free; the "chunked" assignment of conv_common.h is applied as a
+// row permutation when staging the weight tile), i.e. the NHWC epilogue is 16-byte vector loads/stores with no
+// LDS transpose, 64 contiguous bytes per pixel per instruction, and a lane's chunks are ready-made MFMA B
+// operands for a chained 1x1 conv (conv_chain.h).
+// LDS rows are BKB (64|128) bytes with the 16-byte chunk index XOR-swizzled by the row so that every
+// ds_read_b128 lane group hits 16 distinct slots; global_load_lds writes LDS lane-linearly, so the
+// swizzle is applied to the per-lane SOURCE address and again on the fragment read (same involution).
+// Pipeline: 2 LDS stages, one barrier per K-tile: loads of tile t+1 fly during the MFMAs of tile t.
+#pragma once
+#include "conv_chain.h"
+#include "conv_tiles.h"
+
+namespace y4 {
+
+template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0, bool PAIR = false>
+__global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel(const ConvK p) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int ES = (DT == Y4_F32) ? 4 : 2;
+    constexpr int BK = BKB / ES;            // K elements per tile
+    constexpr int CPR = BKB / 16;           // 16-byte chunks per LDS row
+    constexpr int EPC = 16 / ES;            // elements per chunk
+    constexpr int RPI = NT / CPR;           // rows staged per block-wide load instruction
+    constexpr int A_IT = (BM + RPI - 1) / RPI;          // last iteration is predicated when BM % RPI != 0
+    constexpr bool A_PART = BM % RPI != 0;
+    constexpr int B_IT = BN >= RPI ? BN / RPI : 1;      // BN < RPI: only the first BN*CPR threads stage weights
+    constexpr bool B_PART = BN < RPI;
+    constexpr int WPX = BM / WM, WCH = BN / WN;
+    constexpr int MREP = WPX / 16, NREP = WCH / 16;
+    constexpr int CPL = 4 * NREP;           // consecutive channels a lane owns
+    constexpr bool PHASED = (NST == 12);     // 2 LDS stages, two wave groups staggered by one of 4 phases per K-tile
+    constexpr int SN = PHASED ? 2 : NST;     // LDS stages
+    constexpr bool PREFRAG = true;           // all fragments of a K-tile are read before its first MFMA (measured: never slower)
+    constexpr int STAGE = (BM + BN) * BKB;
+    constexpr int KSTEPS = BKB / 64;        // MFMA k-steps (4 chunks each) per tile
+    static_assert(BM % 16 == 0 && (BN % RPI == 0 || (RPI % BN == 0 && (BN * CPR) % 64 == 0)), "tile rows vs rows-per-iteration");
+    static_assert(MREP >= 1 && NREP >= 1, "wave tile");
+    constexpr int LPT = A_IT + B_IT;        // LDS-DMA instructions a wave issues per stage
+    static_assert(SN >= 2 && SN <= 4 && (SN == 2 || !B_PART), "deep pipelines need uniform weight loads per wave");
+    static_assert((SN - 2) * LPT <= 63, "vmcnt field");
+    static_assert(!PHASED || (NT == 512 && KSTEPS == 2), "phased schedule: 8 waves, 128-byte K rows");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous run of tiles with the
+    //      channel tile fastest, so blocks sharing an activation row panel share an L2 (speed only).
+    const int nwg = p.grid_m * p.grid_n;
+    int t;
+    {
+        const int b = blockIdx.x, qq = nwg >> 3, rr = nwg & 7, xcd = b & 7, idx = b >> 3;
+        t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int tile_m = (int)fastdiv((uint32_t)t, p.div_gridn), tile_n = t - tile_m * p.grid_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    ChainPrefetch<CHAIN != 0 ? MREP : 1> chain_pf;
+    if constexpr (CHAIN != 0) {
+        chain_stage_weights<CHAIN, WM * WN>(p, smem + SN * STAGE, __builtin_amdgcn_readfirstlane(wave), lane);
+        chain_prefetch<DT, MREP, CHAIN>(p, chain_pf, m0 + wm * WPX + (lane & 15), p.M, lane);
+    }
+
+    // ---- staging set-up: this thread copies physical chunk slot `q` of rows r0 + j*RPI.
+    // Loads are buffer_load_dwordx4 ... lds through two raw buffer descriptors (activations, weights): the
+    // per-lane byte offset is fixed per (row, tap), the K-tile advance (c0) rides in the scalar soffset, and a
+    // tap that falls into the padding (or a row past M) gets an out-of-range voffset, which the hardware
+    // bounds check turns into zeros -- no per-tile address arithmetic, no zero page.
+    const int q = tid % CPR, r0 = tid / CPR;
+    int a_off[A_IT], a_hi[A_IT], a_wi[A_IT];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) {
+        const int row = r0 + j * RPI;
+        const int m = m0 + row;
+        const int mm = m < p.M ? m : 0;
+        const int n = (int)fastdiv((uint32_t)mm, p.div_howo), rem = mm - n * HoWo;
+        const int ho = (int)fastdiv((uint32_t)rem, p.div_wo), wo = rem - ho * p.Wo;
+        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        a_off[j] = (((n * p.H + hi0) * p.W + wi0) * p.in_cstride + p.in_coff + ((q ^ swz<CPR>(row)) * EPC)) * ES;
+        a_hi[j] = m < p.M ? hi0 : -100000;     // rows past M never validate -> zeros
+        a_wi[j] = wi0;
+    }
+    int b_off[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        const int row = B_PART ? (r0 % BN) : (r0 + j * RPI);
+        // LDS row (wave block, fragment jn, MFMA row i = g*4 + r)  <-  channel of the chunked layout (conv_common.h)
+        const int wb = row / WCH, pr = row - wb * WCH;
+        const int jn = pr >> 4, i = pr & 15, g = i >> 2, r = i & 3;
+        const int ch = chunk_channel(n0 + wb * WCH, jn >> 1, g) + (jn & 1) * 4 + r;
+        b_off[j] = (ch * p.K + ((q ^ swz<CPR>(row)) * EPC)) * ES;
+    }
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(p.wt, p.wt_bytes);
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);          // provably uniform -> SALU/M0 path
+
+    // wave-uniform: does this wave skip the (partial) last A iteration?  (rows r0 + (A_IT-1)*RPI >= BM)
+    const bool a_skip = A_PART && __builtin_amdgcn_readfirstlane(r0 + (A_IT - 1) * RPI >= BM ? 1 : 0) != 0;
+    int ky = 0, kx = 0, c0b = 0, ktb = 0;          // staging cursor: tap, byte offset of c0, byte offset of k in the weights
+    int a_vo[A_IT];
+    auto set_tap = [&]() {
+        const int tap_off = ((ky * p.W + kx) * p.in_cstride) * ES;
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            const bool ok = (unsigned)(a_hi[j] + ky) < (unsigned)p.H && (unsigned)(a_wi[j] + kx) < (unsigned)p.W;
+            a_vo[j] = ok ? a_off[j] + tap_off : (int)0x80000000;            // >= num_records -> reads as zero
+        }
+    };
+    set_tap();
+    auto stage = [&](int buf) {
+        const int da = buf * STAGE + wave_lds;
+        const int db = da + BM * BKB;
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j)
+            if (!A_PART || r0 + j * RPI < BM)                                // wave-uniform (8 rows per wave, BM % 16 == 0)
+                buffer_load16_lds(rs_in, smem + da + j * (NT * 16), a_vo[j], c0b);
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j)
+            if (!B_PART || tid < BN * CPR)                                   // wave-uniform predicate
+                buffer_load16_lds(rs_wt, smem + db + j * (NT * 16), b_off[j], ktb);
+        ktb += BKB;
+        c0b += BKB;
+        if (c0b >= p.Cin * ES) {
+            c0b = 0;
+            if (++kx >= p.ksize) { kx = 0; ++ky; }
+            set_tap();
+        }
+    };
+
+    // ---- fragment read addresses (row & swizzle depend on the lane only)
+    const int frow = lane & 15, fg = lane >> 4;
+    int xo[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) xo[kk] = frow * BKB + (((kk * 4 + fg) ^ swz<CPR>(frow)) * 16);
+    const char* const lds_x = smem + (wm * WPX) * BKB;
+    const char* const lds_w = smem + BM * BKB + (wn * WCH) * BKB;
+
+    f32x4 acc[MREP][NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    if constexpr (PHASED) {
+        // Staggered 4-phase schedule for one 8-wave workgroup per CU.  A K-tile is READ(k-step 0) | MMA | READ(k-step 1) |
+        // MMA with a workgroup barrier after every phase; waves 4-7 run ONE phase behind waves 0-3 (they take one
+        // extra barrier first, waves 0-3 one extra at the end), so while one group's 4 waves (one per SIMD) issue
+        // MFMAs the other group's 4 waves read their fragments from LDS: the matrix pipe and the LDS port are busy
+        // at the same time instead of alternately.  Stage hazards (2 LDS stages):
+        //   group 0 issues tile t+1's loads at the start of its tile t   (both groups have finished reading t-1),
+        //   group 1 issues tile t+2's loads at the start of its last MMA phase of tile t,
+        //   each wave waits for its own loads (vmcnt(0)) before the barrier that precedes the first read of them.
+        auto phase_barrier = [] {
+            asm volatile("s_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto wait_loads = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        const bool grp1 = __builtin_amdgcn_readfirstlane(wave >= 4 ? 1 : 0) != 0;
+        stage(0);
+        wait_loads();
+        phase_barrier();
+        if (grp1) {
+            if (nk > 1) stage(1);
+            phase_barrier();
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sx = lds_x + (kt & 1) * STAGE;
+            const char* sw = lds_w + (kt & 1) * STAGE;
+            u32x4 xf[MREP], wf[NREP];
+            if (!grp1 && kt + 1 < nk) stage((kt + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) xf[i] = *(const u32x4*)(sx + i * 16 * BKB + xo[0]);
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) wf[j] = *(const u32x4*)(sw + j * 16 * BKB + xo[0]);
+            phase_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc[i][j], wf[j], xf[i]);
+            __builtin_amdgcn_s_setprio(0);
+            phase_barrier();
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) xf[i] = *(const u32x4*)(sx + i * 16 * BKB + xo[1]);
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) wf[j] = *(const u32x4*)(sw + j * 16 * BKB + xo[1]);
+            if (grp1) wait_loads();
+            phase_barrier();
+            if (grp1 && kt + 2 < nk) stage(kt & 1);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc[i][j], wf[j], xf[i]);
+            __builtin_amdgcn_s_setprio(0);
+            if (!grp1) wait_loads();
+            phase_barrier();
+        }
+        if (!grp1) phase_barrier();
+    } else {
+    // NST-stage ring: tiles kt+1 .. kt+NST-2 stay in flight (counted vmcnt, never drained in steady state)
+    // while tile kt is consumed; ONE barrier per K-tile: it proves tile kt has landed for every wave and
+    // that every wave is done reading the stage (tile kt-1's) that the next stage() call overwrites.
+#pragma unroll
+    for (int s = 0; s < SN - 1; ++s)
+        if (s < nk) stage(s);
+    int cur = 0, nxt = SN - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = nk - 1 - kt;         // tiles issued after kt so far (capped at NST-2)
+        if (SN == 2 || ahead == 0) wait_vmcnt_then_barrier<0>();
+        else if (a_skip) {                     // this wave issues one load fewer per stage (partial last A iteration)
+            if (SN == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT - 1>();
+            else wait_vmcnt_then_barrier<2 * (LPT - 1)>();
+        } else if (SN == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT>();
+        else wait_vmcnt_then_barrier<2 * LPT>();
+        if (kt + SN - 1 < nk) stage(nxt);
+        const char* sx = lds_x + cur * STAGE;
+        const char* sw = lds_w + cur * STAGE;
+        cur = cur + 1 == SN ? 0 : cur + 1;
+        nxt = nxt + 1 == SN ? 0 : nxt + 1;
+        if constexpr (PREFRAG) {
+            // issue every fragment read of the K-tile first: the reads of k-step 1 then fly behind the MFMAs of
+            // k-step 0 (the compiler's counted lgkmcnt waits keep the order), at the price of a second fragment set
+            u32x4 xf[KSTEPS][MREP], wf[KSTEPS][NREP];
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) xf[kk][i] = *(const u32x4*)(sx + i * 16 * BKB + xo[kk]);
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) wf[kk][j] = *(const u32x4*)(sw + j * 16 * BKB + xo[kk]);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk)
+#pragma unroll
+                for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                    for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc[i][j], wf[kk][j], xf[kk][i]);
+            __builtin_amdgcn_s_setprio(0);
+        } else
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            u32x4 xf[MREP], wf[NREP];
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) xf[i] = *(const u32x4*)(sx + i * 16 * BKB + xo[kk]);
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) wf[j] = *(const u32x4*)(sw + j * 16 * BKB + xo[kk]);
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc[i][j], wf[j], xf[i]);
+        }
+    }
+    }
+
+    // ---- epilogue (conv_common.h): scale/shift, activation, residual, packed converts, slice / upsampled / split store
+    if constexpr (CHAIN != 0) {
+        // chained 1x1 convs consume the tile straight from the accumulators (conv_chain.h)
+        static_assert(WN == 1 && BN == 16 * ChainShape<CHAIN>::HEAD_NREP && DT != Y4_F32,
+                      "chain head: one wave column over all its output channels, 16-bit");
+        chain_epilogue<DT, MREP, CHAIN>(p, smem + SN * STAGE, acc, chain_pf, m0 + wm * WPX + frow, p.M, lane);
+    } else if constexpr (PAIR) {
+        // ---- LDS pair: this conv's tile stays in LDS (as BN/64 panels in the K loop's pixel-operand layout) and the
+        // following 1x1 conv (BN -> BN channels, ordinary packed weights) runs from it with the same fragment reads and
+        // the same K order as its own kernel would -- bit-identical, one launch and one HBM read less.
+        static_assert(BKB == 128 && DT != Y4_F32 && SN == 2 && !PHASED && !B_PART, "LDS pair: plain 2-stage, 128-byte rows");
+        constexpr int XPANEL = BM * 128, NK2 = BN / 64, XBYTES = NK2 * XPANEL, W2STAGE = BN * 128;
+        __syncthreads();                                   // every wave is done with the stage buffers X overwrites
+        char* const xl = smem;
+        const int xrow = wm * WPX + frow, mrow = m0 + xrow, chw = wn * WCH;
+        // tail weights: same row permutation as the head's weight tile, tail_k contiguous elements per channel row
+        int b2_off[B_IT];
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const int row = r0 + j * RPI;
+            const int wb = row / WCH, pr = row - wb * WCH;
+            const int jn = pr >> 4, i = pr & 15, g = i >> 2, r = i & 3;
+            const int ch = chunk_channel(wb * WCH, jn >> 1, g) + (jn & 1) * 4 + r;
+            b2_off[j] = (ch * p.tail_k + ((q ^ swz<CPR>(row)) * EPC)) * ES;
+        }
+        const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(p.tail[0].w, p.tail_w_bytes);
+        auto stage_w2 = [&](int buf, int kt) {
+#pragma unroll
+            for (int j = 0; j < B_IT; ++j)
+                buffer_load16_lds(rs_w2, smem + XBYTES + buf * W2STAGE + wave_lds + j * (NT * 16), b2_off[j], kt * BKB);
+        };
+        stage_w2(0, 0);                                    // its round trip hides under the head's epilogue
+        conv_epilogue<DT, MREP, NREP, true>(p, acc, mrow, p.M, chw, fg, m0 + BM <= p.M, xl, xrow, XPANEL);
+        __syncthreads();                                   // X complete (ds_write -> lgkmcnt(0) -> barrier)
+        f32x4 acc2[MREP][NREP];
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nk2 = p.tail_k >> 6;                     // K-tiles of the tail: its input is panels tail_panel0 .. +nk2-1
+        for (int kt = 0; kt < nk2; ++kt) {
+            wait_vmcnt_then_barrier<0>();
+            if (kt + 1 < nk2) stage_w2((kt + 1) & 1, kt + 1);
+            const char* sx = xl + (p.tail_panel0 + kt) * XPANEL + (wm * WPX) * BKB;
+            const char* sw = smem + XBYTES + (kt & 1) * W2STAGE + (wn * WCH) * BKB;
+            u32x4 xf[KSTEPS][MREP], wf[KSTEPS][NREP];
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) xf[kk][i] = *(const u32x4*)(sx + i * 16 * BKB + xo[kk]);
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) wf[kk][j] = *(const u32x4*)(sw + j * 16 * BKB + xo[kk]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk)
+#pragma unroll
+                for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                    for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc2[i][j], wf[kk][j], xf[kk][i]);
+        }
+        // tail epilogue through the ordinary path: a ConvK that describes the 1x1 conv's output side
+        ConvK p2 = p;
+        p2.scale = p.tail[0].scale; p2.shift = p.tail[0].shift; p2.act = p.tail_act; p2.res = nullptr;
+        p2.out = p.fin; p2.out_cstride = p.fin_cstride; p2.out_coff = p.fin_coff;
+        p2.cout_store = p.tail[0].cout; p2.upsample = 0; p2.out_f32 = p.pair >> 1;
+        p2.split = p.tail_split; p2.out2 = p.fin2; p2.out2_cstride = p.fin2_cstride; p2.out2_coff = p.fin2_coff;
+        conv_epilogue<DT, MREP, NREP>(p2, acc2, mrow, p.M, chw, fg, (m0 + BM <= p.M) && BN <= p2.cout_store);
+        if (p.store_x) pair_store_tile<DT, MREP, NREP>(p, xl, xrow, XPANEL, mrow, p.M, chw, fg);
+    } else {
+        const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.cout_store);
+        conv_epilogue<DT, MREP, NREP>(p, acc, m0 + wm * WPX + frow, p.M, n0 + wn * WCH, fg, full);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- launch
+template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0, bool PAIR = false>
+static int launch_cfg(const ConvK& k, hipStream_t stream) {
+    constexpr int lds_main = (NST == 12 ? 2 : NST) * (BM + BN) * BKB + (CHAIN ? ChainShape<CHAIN ? CHAIN : 1>::LDS_BYTES : 0);
+    constexpr int lds_pair = PAIR ? (BN / 64) * BM * 128 + 2 * BN * 128 : 0;     // tile panels + two weight stages of the tail
+    constexpr int lds = lds_main > lds_pair ? lds_main : lds_pair;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = conv_igemm_kernel<DT, BM, BN, WM, WN, BKB, NST, CHAIN, PAIR>;
+    if (lds > 48 * 1024) {
+        static PerDeviceOnce once;
+        if (const uint64_t bit = once.due()) {
+            Y4_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            once.mark(bit);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(k.grid_m * k.grid_n), dim3(64 * WM * WN), lds, stream, k);
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+// plain tiles of one dtype (one translation unit per dtype: conv_igemm_<dt>.hip)
+template <int DT>
+static int launch_plain(int tile, const ConvK& k, hipStream_t s) {
+    // the fp32 (parity) path instantiates only the first F32_TILES configurations (build time)
+#define Y4_TILE_CASE(id, bm, bn, wm, wn, bkb, nst)                                            \
+    case id:                                                                                  \
+        if constexpr (DT == Y4_F32 && (id > F32_TILES)) break;                                \
+        else return launch_cfg<DT, bm, bn, wm, wn, bkb, nst>(k, s);
+    switch (tile) { Y4_TILES(Y4_TILE_CASE) }
+    set_error("conv2d: tile id %d is not available for this dtype", tile);
+    return Y4_EINVAL;
+}
+
+// chain heads and LDS-pair heads of one 16-bit dtype (conv_igemm_<dt>_fused.hip)
+template <int DT>
+static int launch_fused(int tile, const ConvK& k, hipStream_t s) {
+    if (k.pair) {
+        if constexpr (DT != Y4_F32) {
+#define Y4_PAIR_CASE(id, bm, bn, wm, wn) case id: return launch_cfg<DT, bm, bn, wm, wn, 128, 2, 0, true>(k, s);
+            switch (tile) {
+                Y4_PAIR_CASE(1, 128, 128, 2, 2) Y4_PAIR_CASE(8, 64, 128, 1, 4) Y4_PAIR_CASE(20, 96, 128, 2, 2)
+                Y4_PAIR_CASE(24, 160, 128, 2, 2) Y4_PAIR_CASE(25, 192, 128, 2, 2) Y4_PAIR_CASE(29, 112, 128, 1, 4)
+                Y4_PAIR_CASE(13, 128, 256, 2, 4) Y4_PAIR_CASE(19, 192, 256, 2, 4) Y4_PAIR_CASE(21, 96, 256, 2, 4)
+                Y4_PAIR_CASE(22, 160, 256, 2, 4)
+            }
+#undef Y4_PAIR_CASE
+        }
+        set_error("conv2d: tile id %d cannot head an LDS pair", tile);
+        return Y4_EINVAL;
+    }
+    if (k.ntail > 0) {
+        if constexpr (DT != Y4_F32) {
+            const int cfg = k.ntail == 1 ? 1 : (k.tail[1].cout == 64 ? 2 : 3);
+#define Y4_CHAIN_CASE(CFG)                                                                   \
+    case CFG:                                                                                \
+        switch (tile) {                                                                      \
+            case 3: return launch_cfg<DT, 128, 64, 4, 1, 128, 2, CFG>(k, s);                 \
+            case 4: return launch_cfg<DT, 128, 64, 4, 1, 64, 2, CFG>(k, s);                  \
+            case 15: return launch_cfg<DT, 128, 64, 4, 1, 64, 4, CFG>(k, s);                 \
+        }                                                                                    \
+        break;
+            switch (cfg) { Y4_CHAIN_CASE(1) Y4_CHAIN_CASE(2) Y4_CHAIN_CASE(3) }
+#undef Y4_CHAIN_CASE
+        }
+        set_error("conv2d: tile id %d cannot head a chain", tile);
+        return Y4_EINVAL;
+    }
+    set_error("conv2d: not a fused launch");
+    return Y4_EINVAL;
+}
+
+}  // namespace y4

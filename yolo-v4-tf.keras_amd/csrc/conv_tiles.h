@@ -1,0 +1,61 @@
+// conv_tiles.h -- the tile configurations of conv_igemm_kernel (shared by the per-dtype kernel translation units and the
+// launcher in conv_igemm.hip).
+#pragma once
+
+namespace y4 {
+
+struct TileCfg {
+    int bm, bn, wm, wn, bkb, nst;
+};
+// id, BM (pixels), BN (channels), WM, WN (wave grid), BKB (bytes of K per LDS row), NST (ring stages).
+// The table is also what tests and the autotuner sweep through y4_conv_desc.tile.
+#define Y4_TILES(X)            \
+    X(1, 128, 128, 2, 2, 128, 2)  \
+    X(2, 128, 128, 2, 2, 64, 2)   \
+    X(3, 128, 64, 4, 1, 128, 2)   \
+    X(4, 128, 64, 4, 1, 64, 2)    \
+    X(5, 128, 32, 4, 1, 128, 2)   \
+    X(6, 128, 32, 4, 1, 64, 2)    \
+    X(7, 256, 128, 4, 2, 128, 2)  \
+    X(8, 64, 128, 1, 4, 128, 2)   \
+    X(9, 64, 128, 1, 4, 64, 2)    \
+    X(10, 64, 64, 2, 2, 128, 2)   \
+    X(11, 64, 64, 2, 2, 64, 2)    \
+    X(12, 64, 256, 1, 4, 128, 2)  \
+    X(13, 128, 256, 2, 4, 128, 2) \
+    X(14, 128, 128, 2, 2, 128, 3) \
+    X(15, 128, 64, 4, 1, 64, 4)   \
+    X(16, 32, 128, 1, 4, 128, 2)  \
+    X(17, 64, 128, 1, 4, 128, 3)  \
+    X(18, 256, 256, 2, 4, 128, 2) \
+    X(19, 192, 256, 2, 4, 128, 2) \
+    X(20, 96, 128, 2, 2, 128, 2)  \
+    X(21, 96, 256, 2, 4, 128, 2)  \
+    X(22, 160, 256, 2, 4, 128, 2) \
+    X(23, 224, 256, 2, 4, 128, 2) \
+    X(24, 160, 128, 2, 2, 128, 2) \
+    X(25, 192, 128, 2, 2, 128, 2) \
+    X(26, 144, 128, 1, 4, 128, 2) \
+    X(27, 80, 128, 1, 4, 128, 2)  \
+    X(28, 48, 128, 1, 4, 128, 2)  \
+    X(29, 112, 128, 1, 4, 128, 2) \
+    X(30, 192, 256, 2, 4, 128, 12) \
+    X(31, 256, 256, 2, 4, 128, 12) \
+    X(32, 224, 256, 2, 4, 128, 12)
+
+#define Y4_TILE_ROW(id, bm, bn, wm, wn, bkb, nst) {bm, bn, wm, wn, bkb, nst},
+static const TileCfg kTiles[] = {Y4_TILES(Y4_TILE_ROW)};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+constexpr int F32_TILES = 12;
+
+// chain heads: the tiles with one wave column over 64 channels
+inline bool chain_tile(int tile) { return tile == 3 || tile == 4 || tile == 15; }
+
+// LDS-pair heads: 128-byte K rows, 2 stages, one channel tile over all of Cout (128 or 256), tile + tail stages in LDS
+inline bool pair_tile(int tile) {
+    switch (tile) { case 1: case 8: case 20: case 24: case 25: case 29: case 13: case 19: case 21: case 22: return true; }
+    return false;
+}
+
+}  // namespace y4

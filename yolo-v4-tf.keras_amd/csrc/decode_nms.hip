@@ -418,12 +418,12 @@ int decode_launch(const DecodeK& k, hipStream_t stream) {
 int nms_launch(const NmsK& k, hipStream_t stream) {
     const size_t lds = nms_lds_bytes(k.max_total);
     Y4_REQUIRE(lds <= 160 * 1024 && k.max_total <= 1024, Y4_EINVAL, "nms: max_total %d needs %zu bytes of LDS", k.max_total, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    if (const uint64_t bit = once.due()) {
         Y4_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         Y4_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         Y4_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        once.mark(bit);
     }
     if (k.max_total <= 128) hipLaunchKernelGGL(nms_kernel<2>, dim3(k.N), dim3(NMS_THREADS), lds, stream, k);
     else if (k.max_total <= 256) hipLaunchKernelGGL(nms_kernel<4>, dim3(k.N), dim3(NMS_THREADS), lds, stream, k);

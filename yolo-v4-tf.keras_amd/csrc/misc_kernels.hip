@@ -335,10 +335,10 @@ static int spp_dispatch(void* buf, int n, int side, int c, hipStream_t stream) {
     constexpr int EPC = Elem<DT>::EPC;
     const size_t lds = (size_t)side * side * 4 * 16 * 4;
     if (c % (4 * EPC) == 0 && lds <= 150 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PerDeviceOnce once;
+        if (const uint64_t bit = once.due()) {
             Y4_CHECK_HIP(hipFuncSetAttribute((const void*)spp_lds_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr_set = true;
+            once.mark(bit);
         }
         hipLaunchKernelGGL(spp_lds_kernel<DT>, dim3(n * (c / (4 * EPC))), dim3(256), lds, stream, (T*)buf, n, side, c);
     } else {

@@ -432,6 +432,19 @@ int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s, i
         return stem_conv_launch(h->cfg.dtype, imgs ? imgs + (size_t)img0 * h->S * h->S * 3 : imgs, n, h->S, h->S,
                                 (const float*)(h->wts + L.w_off), scale, shift, L.d.cout, L.d.act,
                                 buf_ptr(h, op.out, img0), op.out.cstride, op.out.coff, s);
+    {
+        // the conv kernels address their input through a raw buffer descriptor (2 GiB range, conv_igemm.hip): a batch
+        // whose input view is larger runs as consecutive image chunks of this same op (images are independent)
+        const int64_t per_img = (int64_t)op.in.side * op.in.side * op.in.cstride * h->es;
+        const int max_n = (int)(((1ll << 31) - 1) / per_img);
+        Y4_REQUIRE(max_n >= 1, Y4_EINVAL, "conv %d: one image's input (%lld B) exceeds the 2 GiB buffer-descriptor range",
+                   op.conv, (long long)per_img);
+        if (n > max_n) {
+            for (int i0 = 0; i0 < n; i0 += max_n)
+                if (int r = run_op(h, op, imgs, n - i0 < max_n ? n - i0 : max_n, s, img0 + i0, allow_chain)) return r;
+            return Y4_OK;
+        }
+    }
     y4_conv_desc d{};
     d.dtype = h->cfg.dtype;
     d.n = n; d.h = op.in.side; d.w = op.in.side; d.cin = op.in.c;
@@ -924,6 +937,30 @@ int y4_get_tiles(y4_handle h, int32_t* tiles, int cap) {
     if (h->fuse_chains)                       // a chained run reports its head as -tile (see y4_set_tiles)
         for (const Chain& ch : h->chains)
             if (ch.enabled) tiles[h->ops[ch.head].conv] = -ch.tile;
+    return Y4_OK;
+}
+
+// does op `oi` launch a kernel of its own under the current fusion settings?  (mirrors run_op's skip logic)
+static bool op_launches(y4_handle h, int oi) {
+    const Op& op = h->ops[oi];
+    if (op.kind != OP_CONV) return true;
+    if (h->fuse_stem && op.conv == 1) return false;
+    if (h->fuse_chains)
+        for (const Chain& ch : h->chains)
+            if (ch.enabled && (ch.tail[0] == oi || ch.tail[1] == oi)) return false;
+    return true;
+}
+
+int y4_launch_counts(y4_handle h, int32_t* conv_family, int32_t* total) {
+    if (int r = check_handle(h)) return r;
+    int convs = 0, all = 2;                                  // decode + nms
+    for (int oi = 0; oi < (int)h->ops.size(); ++oi) {
+        if (!op_launches(h, oi)) continue;
+        ++all;
+        if (h->ops[oi].kind == OP_CONV) ++convs;
+    }
+    if (conv_family) *conv_family = convs;
+    if (total) *total = all;
     return Y4_OK;
 }
 

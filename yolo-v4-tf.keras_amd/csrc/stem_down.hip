@@ -247,11 +247,11 @@ static int stem_down_dispatch(const StemDownK& k, hipStream_t stream) {
     const int blocks = k.N * (k.S / 2);
 #define Y4_SD_CASE(M)                                                                                        \
     case M: {                                                                                                \
-        static bool attr_set = false;                                                                        \
-        if (!attr_set) {                                                                                     \
+        static PerDeviceOnce once;                                                                           \
+        if (const uint64_t bit = once.due()) {                                                               \
             Y4_CHECK_HIP(hipFuncSetAttribute((const void*)stem_down_kernel<DT, M>,                          \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));       \
-            attr_set = true;                                                                                 \
+            once.mark(bit);                                                                                  \
         }                                                                                                    \
         hipLaunchKernelGGL((stem_down_kernel<DT, M>), dim3(blocks), dim3(64 * SD_WAVES), lds, stream, k);              \
         break;                                                                                               \

@@ -73,18 +73,38 @@ def load_weights_distributed(engine, make_flat, src=0):
 
 
 def gather_results(outs, n_total=None):
-    """all_gather per-rank NMS outputs (tensors with the image dimension first, equal shard sizes) and
-    concatenate them in rank order; returns numpy arrays on every rank."""
+    """all_gather per-rank NMS outputs (tensors with the image dimension first) and concatenate them in rank order;
+    returns numpy arrays on every rank.  Shards made by `shard_range` may differ by one image when the batch does not
+    divide by the world size, and all_gather needs equal shapes: every rank pads its rows to the largest shard, the
+    shard sizes travel in a first (tiny) all_gather, and each rank's padding is stripped before concatenation.
+    `n_total` (optional) is checked against the gathered row count."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return [o.cpu().numpy() if hasattr(o, "cpu") else np.asarray(o) for o in outs]
+        res = [o.cpu().numpy() if hasattr(o, "cpu") else np.asarray(o) for o in outs]
+        if n_total is not None and res and res[0].shape[0] != n_total:
+            raise ValueError(f"gather_results: {res[0].shape[0]} rows, expected {n_total}")
+        return res
+    world = dist.get_world_size()
+    rows = int(outs[0].shape[0])
+    mine = torch.tensor([rows], dtype=torch.int64, device=outs[0].device)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine)
+    sizes = [int(t.item()) for t in sizes]
+    cap = max(sizes)
+    if n_total is not None and sum(sizes) != n_total:
+        raise ValueError(f"gather_results: shards {sizes} sum to {sum(sizes)}, expected {n_total}")
     res = []
     for o in outs:
-        parts = [torch.empty_like(o) for _ in range(dist.get_world_size())]
-        dist.all_gather(parts, o.contiguous())
-        cat = torch.cat(parts, dim=0)
-        res.append(cat.cpu().numpy()[:n_total] if n_total is not None else cat.cpu().numpy())
+        o = o.contiguous()
+        if int(o.shape[0]) != rows:
+            raise ValueError("gather_results: outputs of one rank must share their first dimension")
+        if rows < cap:
+            pad = torch.zeros((cap - rows,) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device)
+            o = torch.cat([o, pad], dim=0)
+        parts = [torch.empty_like(o) for _ in range(world)]
+        dist.all_gather(parts, o)
+        res.append(torch.cat([p[:sizes[r]] for r, p in enumerate(parts)], dim=0).cpu().numpy())
     return res
 
 

@@ -198,6 +198,18 @@ class Engine:
                 torch.empty((n,), dtype=torch.int32, device=self.device),
                 torch.empty((n, T), dtype=torch.int32, device=self.device))
 
+    def alloc_outputs_flat(self, n):
+        """The five outputs of `alloc_outputs` as views of ONE int32 device block, so that a step's results return to
+        the host in a single copy: -> (flat int32 tensor, (boxes, scores, classes, valid, kept) views)."""
+        torch = self.torch
+        T = self.T
+        sizes = [n * T * 4, n * T, n * T, n, n * T]
+        offs = np.cumsum([0] + sizes)
+        flat = torch.empty(int(offs[-1]), dtype=torch.int32, device=self.device)
+        v = [flat[offs[i]:offs[i + 1]] for i in range(5)]
+        return flat, (v[0].view(torch.float32).view(n, T, 4), v[1].view(torch.float32).view(n, T),
+                      v[2].view(torch.float32).view(n, T), v[3], v[4].view(n, T))
+
     def decode_nms_device(self, n, outs=None, iou_threshold=-1.0, score_threshold=-1.0):
         outs = outs or self.alloc_outputs(n)
         b, s, c, v, k = outs
@@ -245,7 +257,8 @@ class Engine:
 
     def predict_stream(self, batches, with_indices=False):
         """Pipelined `inference_model.predict` over an iterable of uint8 batches ([n,h,w,3] numpy arrays or pinned torch
-        tensors, n <= max_batch, any h,w): yields one result list per batch, in order.  While batch i computes, batch i+1 crosses PCIe as uint8
+        tensors, n <= max_batch, any h,w): yields one result list per batch, in order.  A pinned tensor is uploaded from where
+        it lies and may be refilled as soon as the generator yields (its upload is waited for before every yield).  While batch i computes, batch i+1 crosses PCIe as uint8
         on a second HIP stream (pinned staging, 4x fewer bytes than float32) and batch i-1's results return to the
         host, so the PCIe-inclusive rate approaches the device rate.  Preprocessing is `y4_preprocess_u8` (bit-identical
         to `Yolov4.preprocess_img`, reference models.py:95-98)."""
@@ -315,6 +328,10 @@ class Engine:
                     down_stream.wait_event(sl["ran"])
                     sl["flat_host"].copy_(sl["flat"], non_blocking=True)
                     sl["done"].record(down_stream)
+                if pinned_in:
+                    # the upload reads the CALLER's pinned tensor: it must have left host memory before control returns
+                    # to a loader that may refill that buffer (the engine's own staging buffer is guarded by sl["free"])
+                    sl["up"].synchronize()
                 if pending is not None:
                     yield finish(pending)
                 pending = sl
@@ -358,12 +375,20 @@ class Engine:
 
     def set_chain_fusion(self, on=True):
         """3x3+Add -> 1x1 (-> 1x1 over the concat) runs of the 64-channel CSP stages as one kernel each (16-bit
-        dtypes).  Returns the number of fused runs.  Equal to the unfused path up to 16-bit rounding, not bitwise."""
+        dtypes).  Returns the number of fused runs.  A chained conv issues the same MFMAs on the same 16-bit inputs in the
+        same order as its own kernel, so every materialised tensor, the heads and the detections are BIT-IDENTICAL to the
+        unfused path (tests/test_gpu_forward.py::test_chain_fusion_is_bit_identical): a pure scheduling knob."""
         r = self.lib.y4_set_chain_fusion(self.handle, int(bool(on)))
         if r < 0:
             ext.check(r)
         self.chain_fusion = bool(on)
         return r
+
+    def conv_launches_per_step(self):
+        """Launches of the conv kernel family (everything but the stem) in one predict under the current settings."""
+        convs, total = C.c_int32(), C.c_int32()
+        ext.check(self.lib.y4_launch_counts(self.handle, C.byref(convs), C.byref(total)))
+        return convs.value
 
     def timing_begin(self, max_steps, coarse=False):
         ext.check(self.lib.y4_timing_begin(self.handle, int(max_steps), int(bool(coarse))))
