@@ -157,6 +157,17 @@ int y4_set_stem_fusion(y4_handle h, int on);
  * accepts the same encoding; > 0 there means separate kernels, 0 fused with the built-in tile). */
 int y4_set_chain_fusion(y4_handle h, int on);
 
+/* Scheduling knob (16-bit dtypes; results unchanged): run the whole first CSP stage -- convs 2..7, reference
+ * custom_layers.py:47-69 (csp_block with residual_bottleneck=True) and the transition conv :105 -- as ONE spatially tiled
+ * kernel (csrc/csp_stage.hip): per 16x16-pixel tile the route / main-in / bottleneck / 3x3+Add / main-out / transition
+ * convs run from LDS and registers, so only conv 1's output is read and conv 7's written.  Every conv issues the same
+ * MFMAs on the same 16-bit inputs in the same order as its own kernel: bit-identical.  Returns 1 when the stage kernel
+ * is active, 0 when off, a negative Y4_E* code on error (Y4_EINVAL for fp32).  y4_autotune afterwards keeps it only if
+ * it measures faster than the separately tuned kernels (y4_get_stage_fusion tells).  While active,
+ * y4_get_conv_output of convs 2..6 fails with Y4_ESTATE (not materialised). */
+int y4_set_stage_fusion(y4_handle h, int on);
+int y4_get_stage_fusion(y4_handle h);
+
 /* Kernel launches of one y4_predict under the current fusion / tile settings (whole batch, no sub-batching):
  * `conv_family` = launches of the conv kernels other than the stem (what bench.py's roofline is quoted on),
  * `total` = all launches including stem, SPP, decode and NMS. */

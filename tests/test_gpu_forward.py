@@ -120,10 +120,11 @@ def test_fp32_forward_and_nms_parity(size, ncls, n):
     eng.close()
 
 
-@pytest.mark.parametrize("dtype,tol,min_common", [("bf16", 0.35, 0.6), ("f16", 0.06, 0.6)])
+@pytest.mark.parametrize("dtype,tol,min_common", [("bf16", 0.45, 0.8), ("f16", 0.06, 0.93)])
 def test_16bit_forward_close_to_fp32_oracle(dtype, tol, min_common):
-    """16-bit storage: heads stay close to the fp32 oracle (bound = observed error budget of 110 layers of
-    8-bit/11-bit mantissa rounding on O(1) logits with std ~1.3), and most detections coincide."""
+    """16-bit storage: heads stay close to the fp32 oracle.  Bounds = measured on MI355X + ~40 % (bf16: 99.9 % quantile of
+    |logit error| 0.27-0.33, mean 0.05-0.06, 92-96 % of detections matched by (box, class); fp16: 0.034-0.042, 0.0064-0.0075,
+    98-99 %); the budget of 110 layers of 8-/11-bit mantissa rounding on logits of std ~1.3."""
     from oracle import forward as OF, decode_nms as OD
     size, ncls, n = 416, 3, 2
     cfg, plan, ws, imgs, eng = _setup(size, ncls, n, dtype)
@@ -134,7 +135,7 @@ def test_16bit_forward_close_to_fp32_oracle(dtype, tol, min_common):
         err = np.abs(a - b)
         assert np.isfinite(a).all()
         measured.append((float(err.mean()), float(np.quantile(err, 0.999))))
-        assert err.mean() < tol / 4 and np.quantile(err, 0.999) < tol, (err.mean(), err.max())
+        assert err.mean() < tol / 5 and np.quantile(err, 0.999) < tol, (err.mean(), err.max())
     boxes, scores, classes, valid, kept = eng.predict(imgs, with_indices=True)
     rb, rs, rc, rv, ri = OD.inference_from_heads(ref_heads, ncls, cfg["anchors"], cfg["xyscale"], size)
     fracs = []
@@ -177,6 +178,7 @@ def test_full_size_properties():
     plain = [o.cpu().numpy() for o in eng.predict_device(dev)]
     eng.set_stem_fusion(True)
     assert eng.set_chain_fusion(True) == 25
+    assert eng.set_stage_fusion(True)
     run1 = [o.cpu().numpy() for o in eng.predict_device(dev)]
     run2 = [o.cpu().numpy() for o in eng.predict_device(dev)]
     for a, b, c in zip(run1, run2, plain):
@@ -294,6 +296,52 @@ def test_chain_fusion_is_bit_identical(dtype, size, n):
     eng.close()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("size,n", [(96, 5), (160, 3), (416, 2), (608, 2)])
+def test_stage_fusion_is_bit_identical(dtype, size, n):
+    """Convs 2..7 (the first CSP stage, reference custom_layers.py:47-69 + :105) as ONE spatially tiled kernel
+    (csrc/csp_stage.hip): 16x16-pixel tiles with a recomputed 1-pixel halo ring, every intermediate in LDS / registers.
+    Each conv issues the same MFMAs on the same 16-bit inputs in the same order as its own kernel, so conv 7's output, every
+    later tensor, the heads and the detections must be bit-identical to the unfused path -- including the image border
+    (conv 5's zero padding is applied to conv 4's OUTPUT, not to the input tile), tiles at every corner, batches that
+    straddle the per-XCD tile ranges, and in combination with the stem fusion, the chain fusions, autotune and
+    sub-batching.  While active, convs 2..6 are not materialised."""
+    import yolo4hip.ext as ext
+    cfg, plan, ws, imgs, eng = _setup(size, 3, n, dtype, seed=8)
+    heads = eng.forward_heads(imgs)
+    taps = (1, 7, 8, 16, 37)
+    ref = {i: eng.conv_output(i, n) for i in taps}
+    base = eng.predict(imgs, with_indices=True)
+
+    def check():
+        for a, b in zip(heads, eng.forward_heads(imgs)):
+            assert np.array_equal(a, b)
+        for i in taps:
+            assert np.array_equal(ref[i], eng.conv_output(i, n)), i
+        for a, b in zip(base, eng.predict(imgs, with_indices=True)):
+            assert np.array_equal(a, b)
+
+    assert eng.set_stage_fusion(True) and eng.stage_fusion_active()
+    check()
+    for idx in (2, 3, 4, 5, 6):
+        with pytest.raises(ext.Y4Error):
+            eng.conv_output(idx, n)
+    eng.set_stem_fusion(True)
+    eng.set_chain_fusion(True)
+    check()
+    if n > 1:
+        eng.set_subbatch(1, 16)
+        check()
+        eng.set_subbatch(0)
+    eng.autotune(n, reps=1)                  # keeps the stage kernel only if it measures faster; either way:
+    check()
+    assert eng.set_stage_fusion(True)        # force it back on with the tuned tiles around it
+    check()
+    assert not eng.set_stage_fusion(False) and not eng.stage_fusion_active()
+    check()
+    eng.close()
+
+
 def test_stem_fusion_rejected_where_unsupported():
     import yolo4hip.ext as ext
     cfg, plan, ws, imgs, eng = _setup(160, 3, 1, "f32")
@@ -301,6 +349,8 @@ def test_stem_fusion_rejected_where_unsupported():
         eng.set_stem_fusion(True)
     with pytest.raises(ext.Y4Error):
         eng.set_chain_fusion(True)
+    with pytest.raises(ext.Y4Error):
+        eng.set_stage_fusion(True)
     eng.close()
 
 

@@ -117,12 +117,15 @@ template <> struct Elem<Y4_F16> {
 template <bool FAST>
 __device__ __forceinline__ float mish_f(float x) {
     if (FAST) {
-        // 16-bit storage paths: tanh(softplus(x)) = 1 - 2/(e*e + 2e + 2) in 7 VALU ops (v_exp_f32 + v_rcp_f32, ~1 ulp
-        // each).  No clamp: e = inf gives rcp = 0 and the factor 1.  The subtraction cancels only for x << 0, where
-        // the absolute error |x| * 1.5e-7 stays below the storage type's resolution (|mish(x)| < 3e-3 for x < -8).
+        // 16-bit storage paths.  With e = exp(x):  tanh(softplus(x)) = 1 - 2/(e*e + 2e + 2), so
+        //     mish(x) = x - x * r,   r = 1 / (e*(e/2 + 1) + 1)   (= 2/(e*e + 2e + 2))
+        // = 5 plain VALU ops + v_exp_f32 + v_rcp_f32 (~1 ulp each), every plain op an FMA/MUL that exists in packed form
+        // (see bn_act4: two elements per instruction).  No clamp: e = inf gives r = 0 and mish = x; e = 0 gives r = 1 and
+        // mish = 0.  The final FMA cancels only for x << 0, where the absolute error |x| * 1.5e-7 stays below the storage
+        // type's resolution (|mish(x)| < 3e-3 for x < -8).  bn_act4's packed sequence is this one, op for op.
         const float e = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
-        const float r = __builtin_amdgcn_rcpf(fmaf(e, e + 2.f, 2.f));
-        return x * fmaf(-2.f, r, 1.f);
+        const float r = __builtin_amdgcn_rcpf(fmaf(e, fmaf(e, 0.5f, 1.f), 1.f));
+        return fmaf(-x, r, x);
     }
     const float e = expf(fminf(x, 20.f));
     const float n = e * (e + 2.f);
@@ -167,6 +170,31 @@ __device__ __forceinline__ float apply_act_t(float x) {
     if (ACT == Y4_ACT_MISH) return mish_f<FAST>(x);
     if (ACT == Y4_ACT_LEAKY) return FAST ? leaky_fast(x) : leaky_f(x);
     return x;
+}
+
+// out[r] = act(a[r] * sc[r] + sh[r]), r < 4 (one MFMA accumulator fragment of a lane): THE epilogue arithmetic of every
+// conv kernel.  Where it is VALU-bound (Mish: the 304^2 / 152^2 stages), the 16-bit paths run it two elements per
+// instruction -- v_pk_fma_f32 / v_pk_mul_f32 issue at the rate of their scalar forms (measured on MI355X: v_fma_f32 4.5,
+// v_pk_fma_f32 4.9 cycles per wave instruction per SIMD; v_exp_f32 / v_rcp_f32 8.5) and are IEEE per element, so the
+// results equal mish_f<true> bit for bit.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <bool FAST, int ACT>
+__device__ __forceinline__ void bn_act4(const f32x4_t& a, const float* sc, const float* sh, float* out) {
+    if constexpr (FAST && ACT == Y4_ACT_MISH) {
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+            const f32x2_t x = __builtin_elementwise_fma(f32x2_t{a[r], a[r + 1]}, f32x2_t{sc[r], sc[r + 1]}, f32x2_t{sh[r], sh[r + 1]});
+            const f32x2_t t = x * 1.4426950408889634f;
+            const f32x2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            const f32x2_t dh = __builtin_elementwise_fma(e, __builtin_elementwise_fma(e, f32x2_t{0.5f, 0.5f}, f32x2_t{1.f, 1.f}), f32x2_t{1.f, 1.f});
+            const f32x2_t rr = {__builtin_amdgcn_rcpf(dh.x), __builtin_amdgcn_rcpf(dh.y)};
+            const f32x2_t y = __builtin_elementwise_fma(-x, rr, x);
+            out[r] = y.x; out[r + 1] = y.y;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[r] = apply_act_t<FAST, ACT>(fmaf(a[r], sc[r], sh[r]));
+    }
 }
 
 }  // namespace y4

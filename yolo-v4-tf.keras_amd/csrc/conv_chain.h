@@ -113,8 +113,7 @@ __device__ __forceinline__ void chain_bn_act_pack(const f32x4 (&acc)[NREP2], con
     float v[NREP2 * 4];
 #pragma unroll
     for (int j = 0; j < NREP2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[j * 4 + r] = apply_act_t<true, Y4_ACT_MISH>(fmaf(acc[j][r], sc[j * 4 + r], sh[j * 4 + r]));
+        bn_act4<true, Y4_ACT_MISH>(acc[j], sc + j * 4, sh + j * 4, v + j * 4);
 #pragma unroll
     for (int c = 0; c < NREP2 / 2; ++c) Elem<DT>::store_chunk(&out[c], v + c * 8);
 }
@@ -144,8 +143,7 @@ __device__ __forceinline__ void chain_epilogue(const ConvK& p, const char* lds_w
         float v[HC * 8];
 #pragma unroll
         for (int j = 0; j < HN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[j * 4 + r] = apply_act_t<true, Y4_ACT_MISH>(fmaf(acc[i][j][r], sc[j * 4 + r], sh[j * 4 + r]));
+            bn_act4<true, Y4_ACT_MISH>(acc[i][j], sc + j * 4, sh + j * 4, v + j * 4);
         if (p.res) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {

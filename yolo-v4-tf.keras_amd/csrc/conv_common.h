@@ -139,12 +139,8 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[
         if (!FULL && m >= m_limit) continue;
         float v[NC * 8];
 #pragma unroll
-        for (int j = 0; j < NREP; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = j * 4 + r;                     // = chunk (j>>1), element (j&1)*4 + r
-                v[k] = apply_act_t<FAST, ACT>(fmaf(acc[i][j][r], sc[k], sh[k]));
-            }
+        for (int j = 0; j < NREP; ++j)                       // v[j*4 + r] = chunk (j>>1), element (j&1)*4 + r
+            bn_act4<FAST, ACT>(acc[i][j], sc + j * 4, sh + j * 4, v + j * 4);
         if (p.res) {
             const T* rp = (const T*)p.res + (int64_t)m * p.res_cstride + p.res_coff;
 #pragma unroll

@@ -55,6 +55,14 @@ int stem_down_launch(int dtype, const float* imgs, int n, int S, const void* ste
                      const float* s0_shift, int act0, const void* w1_packed, const float* s1_scale, const float* s1_shift,
                      int act1, void* out, int out_cstride, int out_coff, hipStream_t stream);
 
+// csp_stage.hip: convs 2..7 (the first CSP stage) as one spatially tiled persistent kernel (16-bit dtypes)
+bool csp_stage_supported(int dtype, int side);
+size_t csp_stage_blob_bytes();
+int pack_csp_stage(int dtype, const float* const* w, const float* const* scale, const float* const* shift, void* blob,
+                   hipStream_t stream);
+int csp_stage_launch(int dtype, const void* in, int n, int side, int in_cstride, int in_coff, const void* blob, void* out,
+                     int out_cstride, int out_coff, hipStream_t stream);
+
 // decode_nms.hip
 // Per-image candidate counters are spaced one per 256 bytes: packed into one cache line, the ~10^3 appends per
 // image of a whole batch serialise on a single L2 line (measured: decode 195 us -> see DESIGN.md).

@@ -105,6 +105,12 @@ struct y4_ctx {
     std::vector<Chain> chains;
     bool fuse_chains = false;
     bool t_recorded_this_call = false;
+    // the first CSP stage (convs 2..7) as one spatially tiled kernel (csp_stage.hip): ops [stage_first, stage_last];
+    // stage_first < 0 when the plan / dtype does not allow it.  `stage_on` = requested, `stage_enabled` = the tuner's verdict
+    int stage_first = -1, stage_last = -1;
+    size_t stage_blob_off = 0;
+    bool stage_on = false, stage_enabled = true;
+    bool stage_active() const { return stage_first >= 0 && stage_on && stage_enabled; }
 };
 
 namespace {
@@ -344,6 +350,42 @@ void find_chains(y4_ctx& c) {
     }
 }
 
+// The first CSP stage in the op list: [route|main-in pair (64+64 over 64)] [1x1 64->32] [3x3 32->64 + Add] [1x1 64->64]
+// [1x1 128->64 over the concat], all Mish -- reference custom_layers.py:47-69 with residual_bottleneck=True, and :105.
+void find_stage(y4_ctx& c) {
+    if (c.cfg.dtype == Y4_F32) return;
+    const int nops = (int)c.ops.size();
+    for (int i = 0; i + 4 < nops; ++i) {
+        const Op &a = c.ops[i], &b = c.ops[i + 1], &d = c.ops[i + 2], &e = c.ops[i + 3], &f = c.ops[i + 4];
+        if (a.kind != OP_CONV || b.kind != OP_CONV || d.kind != OP_CONV || e.kind != OP_CONV || f.kind != OP_CONV) continue;
+        if (a.conv2 < 0 || b.conv2 >= 0 || d.conv2 >= 0 || e.conv2 >= 0 || f.conv2 >= 0) continue;
+        const Layer &la = c.layers[a.conv], &la2 = c.layers[a.conv2], &lb = c.layers[b.conv], &ld = c.layers[d.conv],
+                    &le = c.layers[e.conv], &lf = c.layers[f.conv];
+        auto mish1x1 = [](const Layer& l, int cin, int cout) {
+            return l.d.ksize == 1 && l.d.cin == cin && l.d.cout == cout && l.d.act == Y4_ACT_MISH && l.d.has_bn;
+        };
+        if (!(mish1x1(la, 64, 64) && mish1x1(la2, 64, 64) && a.split == 64 && mish1x1(lb, 64, 32) && mish1x1(le, 64, 64) &&
+              mish1x1(lf, 128, 64)))
+            continue;
+        if (!(ld.d.ksize == 3 && ld.d.stride == 1 && ld.d.cin == 32 && ld.d.cout == 64 && ld.d.act == Y4_ACT_MISH && d.has_res)) continue;
+        // dataflow: b reads a's main-in half, d reads b and adds a's main-in half, e reads d, f reads [e | a's route half]
+        if (!(same_view(b.in, a.out2) && same_view(d.in, b.out) && same_view(d.res, a.out2) && same_view(e.in, d.out))) continue;
+        if (!(f.in.buf == e.out.buf && f.in.buf == a.out.buf && e.out.coff == f.in.coff && a.out.coff == f.in.coff + 64 && f.in.c == 128)) continue;
+        if (a.upsample || f.upsample || f.out_f32 || a.in.side % 16 != 0) continue;
+        // no other op may read the tensors that stop existing
+        bool leak = false;
+        for (int k = 0; k < nops; ++k) {
+            if (k >= i && k <= i + 4) continue;
+            const Op& o = c.ops[k];
+            for (int bufid : {a.out.buf, a.out2.buf, b.out.buf, d.out.buf})
+                if (o.in.buf == bufid || (o.has_res && o.res.buf == bufid)) leak = true;
+        }
+        if (leak) continue;
+        c.stage_first = i; c.stage_last = i + 4;
+        return;
+    }
+}
+
 void layout(y4_ctx& c) {
     // ---- activations
     size_t off = 0;
@@ -371,6 +413,7 @@ void layout(y4_ctx& c) {
         L.shift_off = off; off = align256(off + rows * 4);
         if (L.has_tail) { L.tail_off = off; off = align256(off + (size_t)L.d.cout * L.d.cin * c.es); }
     }
+    if (c.stage_first >= 0) { c.stage_blob_off = off; off = align256(off + csp_stage_blob_bytes()); }
     c.wts_bytes = off;
 }
 
@@ -421,6 +464,23 @@ int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s, i
                                 buf_ptr(h, o1.out, img0), o1.out.cstride, o1.out.coff, s);
     }
     if (h->fuse_stem && op.kind == OP_CONV && op.conv == 1) return Y4_OK;
+    if (allow_chain && h->stage_active() && op.kind == OP_CONV) {
+        const int oi = (int)(&op - h->ops.data());
+        if (oi > h->stage_first && oi <= h->stage_last) return Y4_OK;      // ran inside the stage kernel
+        if (oi == h->stage_first) {
+            const Op& last = h->ops[h->stage_last];
+            const int64_t per_img = (int64_t)op.in.side * op.in.side * op.in.cstride * h->es;
+            const int max_n = (int)(((1ll << 31) - 1) / per_img);
+            for (int i0 = 0; i0 < n; i0 += max_n) {           // 2 GiB buffer-descriptor range: image chunks
+                const int cnt = n - i0 < max_n ? n - i0 : max_n;
+                if (int r = csp_stage_launch(h->cfg.dtype, buf_ptr(h, op.in, img0 + i0), cnt, op.in.side, op.in.cstride, op.in.coff,
+                                             h->wts + h->stage_blob_off, buf_ptr(h, last.out, img0 + i0), last.out.cstride,
+                                             last.out.coff, s))
+                    return r;
+            }
+            return Y4_OK;
+        }
+    }
     const Chain* chain = nullptr;
     if (h->fuse_chains && allow_chain && op.kind == OP_CONV)
         for (const Chain& ch : h->chains) {
@@ -567,6 +627,7 @@ int y4_create(const y4_config* cfg, y4_handle* out) {
     }
     Builder(*c).build();
     find_chains(*c);
+    find_stage(*c);
     layout(*c);
     *out = c;
     return Y4_OK;
@@ -641,6 +702,21 @@ int y4_pack_weights(y4_handle h, const float* blob, size_t n_floats, void* strea
                 if (int r = pack_tail_weights(h->cfg.dtype, L.d.cout, L.d.cin, w, h->wts + L.tail_off, s)) return r;
         }
     }
+    if (h->stage_first >= 0) {
+        // convs 2..7 once more, as the fragment-ordered blob of csp_stage_kernel (same rounding of the same floats)
+        const Op& a = h->ops[h->stage_first];
+        const int convs[6] = {a.conv, a.conv2, h->ops[h->stage_first + 1].conv, h->ops[h->stage_first + 2].conv,
+                              h->ops[h->stage_first + 3].conv, h->ops[h->stage_first + 4].conv};
+        const float *w[6], *sc[6], *sh[6];
+        for (int k = 0; k < 6; ++k) {
+            const Layer& L = h->layers[convs[k]];
+            const Layer& D = L.fused_with >= 0 ? h->layers[L.fused_with] : L;
+            w[k] = blob + L.d.weight_offset + 4 * (int64_t)L.d.cout;
+            sc[k] = (const float*)(h->wts + D.scale_off) + L.fused_row;
+            sh[k] = (const float*)(h->wts + D.shift_off) + L.fused_row;
+        }
+        if (int r = pack_csp_stage(h->cfg.dtype, w, sc, sh, h->wts + h->stage_blob_off, s)) return r;
+    }
     h->weights_ready = true;
     return Y4_OK;
 }
@@ -693,6 +769,11 @@ int y4_get_conv_output(y4_handle h, int conv_idx, int n, float* out, size_t out_
     for (const Op& op : h->ops) {
         if (op.kind == OP_SPP || (op.conv != conv_idx && op.conv2 != conv_idx)) continue;
         Y4_REQUIRE(!(h->fuse_stem && conv_idx == 0), Y4_ESTATE, "conv 0 is not materialised while stem fusion is on");
+        {
+            const int oi = (int)(&op - h->ops.data());
+            Y4_REQUIRE(!(h->stage_active() && oi >= h->stage_first && oi < h->stage_last), Y4_ESTATE,
+                       "conv %d is not materialised while the stage fusion is on", conv_idx);
+        }
         const View& v = op.conv == conv_idx ? op.out : op.out2;
         const int64_t px = (int64_t)n * v.side * v.side;   // for an upsampling conv: the upsampled tensor
         Y4_REQUIRE((int64_t)out_floats >= px * v.c, Y4_EINVAL, "output buffer too small: %zu < %lld", out_floats,
@@ -793,6 +874,7 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
         return ms;
     };
     auto images_of = [&](int oi) { return (h->sub_images > 0 && oi <= h->sub_last_op && n > h->sub_images) ? h->sub_images : n; };
+    h->stage_enabled = false;          // passes 1 and 2 tune the stage's convs as separate kernels; pass 3 decides
     // pass 1: every conv as its own kernel
     std::vector<float> best_ms(h->ops.size(), 0.f);
     for (int oi = 0; oi < (int)h->ops.size() && rc == Y4_OK; ++oi) {
@@ -859,6 +941,30 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
             }
             ch.enabled = t_fused < t_sep;
         }
+    // pass 3: the stage kernel (convs 2..7 in one launch) head to head against the same ops as tuned above
+    if (rc == Y4_OK && h->stage_first >= 0 && h->stage_on) {
+        const int ne = images_of(h->stage_first);
+        const int rounds = 4, per_round = reps > 3 ? reps : 3;
+        auto block = [&](bool fused) -> float {
+            h->stage_enabled = fused;
+            if (hipEventRecord(e0, s) != hipSuccess) return -2.f;
+            for (int i = 0; i < per_round; ++i)
+                for (int oi = h->stage_first; oi <= h->stage_last; ++oi) run_op(h, h->ops[oi], nullptr, ne, s, 0, true);
+            float ms = 0.f;
+            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+                return -2.f;
+            return ms;
+        };
+        float t_fused = 0.f, t_sep = 0.f;
+        block(true); block(false);
+        for (int r = 0; r < rounds && rc == Y4_OK; ++r) {
+            const float a = block(true), b = block(false);
+            if (a == -2.f || b == -2.f) { rc = Y4_EHIP; break; }
+            t_fused += a; t_sep += b;
+        }
+        h->stage_enabled = rc == Y4_OK && t_fused < t_sep;
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc != Y4_OK) set_error("y4_autotune: HIP event failure");
@@ -925,6 +1031,20 @@ int y4_set_chain_fusion(y4_handle h, int on) {
     return on ? (int)h->chains.size() : Y4_OK;
 }
 
+int y4_set_stage_fusion(y4_handle h, int on) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(h->t_max_steps == 0, Y4_ESTATE, "y4_set_stage_fusion: a timing session is open");
+    Y4_REQUIRE(!on || h->stage_first >= 0, Y4_EINVAL, "y4_set_stage_fusion: needs a 16-bit dtype (dtype %d)", h->cfg.dtype);
+    h->stage_on = on != 0;
+    h->stage_enabled = true;
+    return h->stage_active() ? 1 : 0;
+}
+
+int y4_get_stage_fusion(y4_handle h) {
+    if (int r = check_handle(h)) return r;
+    return h->stage_active() ? 1 : 0;
+}
+
 int y4_get_tiles(y4_handle h, int32_t* tiles, int cap) {
     if (int r = check_handle(h)) return r;
     Y4_REQUIRE(tiles && cap >= (int)h->layers.size(), Y4_EINVAL, "y4_get_tiles: need room for %d layers", (int)h->layers.size());
@@ -945,6 +1065,7 @@ static bool op_launches(y4_handle h, int oi) {
     const Op& op = h->ops[oi];
     if (op.kind != OP_CONV) return true;
     if (h->fuse_stem && op.conv == 1) return false;
+    if (h->stage_active() && oi >= h->stage_first && oi <= h->stage_last) return oi == h->stage_first;
     if (h->fuse_chains)
         for (const Chain& ch : h->chains)
             if (ch.enabled && (ch.tail[0] == oi || ch.tail[1] == oi)) return false;

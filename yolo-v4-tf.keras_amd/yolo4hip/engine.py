@@ -384,6 +384,20 @@ class Engine:
         self.chain_fusion = bool(on)
         return r
 
+    def set_stage_fusion(self, on=True):
+        """Convs 2..7 (the 304^2 CSP stage at 608) as one spatially tiled kernel (16-bit dtypes; bit-identical results).
+        Returns whether the stage kernel is active; `autotune` afterwards keeps it only if it measures faster."""
+        r = self.lib.y4_set_stage_fusion(self.handle, int(bool(on)))
+        if r < 0:
+            ext.check(r)
+        return bool(r)
+
+    def stage_fusion_active(self):
+        r = self.lib.y4_get_stage_fusion(self.handle)
+        if r < 0:
+            ext.check(r)
+        return bool(r)
+
     def conv_launches_per_step(self):
         """Launches of the conv kernel family (everything but the stem) in one predict under the current settings."""
         convs, total = C.c_int32(), C.c_int32()
