@@ -29,9 +29,11 @@ for k, v in sorted(agg.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", 0) + kv
     if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
         row["hbm_read_bytes_per_step"] = 2 * v.get("FETCH_SIZE", 0.0) * 1024 / steps
         row["hbm_write_bytes_per_step"] = v.get("WRITE_SIZE", 0.0) * 1024 / steps
-        if "conv_igemm" in k:
+        if "conv_igemm" in k or "csp_stage" in k:
             tot_f += row["hbm_read_bytes_per_step"]; tot_w += row["hbm_write_bytes_per_step"]
     rows.append(row)
-json.dump({"steps_profiled": steps, "conv_igemm_hbm_read_bytes_per_step": tot_f, "conv_igemm_hbm_write_bytes_per_step": tot_w,
+json.dump({"config": {"size": 608, "classes": 80, "batch": 32, "dtype": "bf16", "stem_fusion": True, "chain_fusion": True,
+                      "stage_fusion": any("csp_stage" in r["kernel"] for r in rows)},
+           "steps_profiled": steps, "conv_igemm_hbm_read_bytes_per_step": tot_f, "conv_igemm_hbm_write_bytes_per_step": tot_w,
            "conv_igemm_hbm_bytes_per_step": tot_f + tot_w, "kernels": rows}, open(out, "w"), indent=1)
 print("conv_igemm family: read %.3f GB + write %.3f GB per step" % (tot_f / 1e9, tot_w / 1e9))
