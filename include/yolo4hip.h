@@ -96,6 +96,11 @@ int y4_adopt_packed_weights(y4_handle h);
 /* Replaces yolo_model.predict(imgs) (reference models.py:50-52,514; graph custom_layers.py:100-198).
  * Raw heads stay inside the workspace (padded to head_cstride channels). */
 int y4_forward(y4_handle h, const float* imgs_nhwc_dev, int n, void* stream);
+/* The same on uint8 frames [n, H, W, 3] ALREADY at network size, BEFORE the `/ 255.` of Yolov4.preprocess_img (reference
+ * models.py:95-98): the stem applies it inside its operand load, so no float image tensor exists and the frames cross
+ * PCIe / HBM at 3 B per pixel.  Bit-identical to y4_forward on float32(double(v) / 255.) for every dtype.
+ * Frames of another size go through y4_resize_u8 (cv2.resize's uint8 INTER_LINEAR arithmetic) first. */
+int y4_forward_u8(y4_handle h, const uint8_t* imgs_nhwc_u8_dev, int n, void* stream);
 /* Dense float32 copies of the three raw heads, [n,g,g,3*(C+5)] each, as Keras returns them. */
 int y4_get_heads(y4_handle h, int n, float* out_s_dev, float* out_m_dev, float* out_l_dev, void* stream);
 /* Inverse of y4_get_heads: load dense float32 raw heads [n,g,g,3*(C+5)] into the workspace, so that
@@ -119,6 +124,9 @@ int y4_decode_nms(y4_handle h, int n, float iou_threshold, float score_threshold
 /* Replaces inference_model.predict(imgs) (reference models.py:69-73,113,159) = forward + decode + NMS. */
 int y4_predict(y4_handle h, const float* imgs_nhwc_dev, int n, float* boxes_dev, float* scores_dev,
                float* classes_dev, int32_t* valid_dev, int32_t* kept_idx_dev, void* stream);
+
+int y4_predict_u8(y4_handle h, const uint8_t* imgs_nhwc_u8_dev, int n, float* boxes_dev, float* scores_dev,
+                  float* classes_dev, int32_t* valid_dev, int32_t* kept_idx_dev, void* stream);
 
 /* Per-op device time of one forward (+decode+NMS) in ms, measured with HIP events on `stream`
  * (synchronises).  `names` receives op names ('c17', 'spp', 'decode', 'nms', ...), 16 bytes each. */
@@ -227,6 +235,9 @@ int y4_stem_conv(int dtype, const float* imgs_dev, int n, int h, int w, const fl
  * uint8 RGB image [h,w,3] -> float32 [out_h,out_w,3] in [0,1], one image slot of the batch tensor y4_forward takes.
  * Saves the 4x fatter float32 host->device copy and the host-side float64 tensor. */
 int y4_preprocess_u8(const uint8_t* img_dev, int h, int w, float* out_dev, int out_h, int out_w, void* stream);
+/* The resize half of preprocess_img alone, batched: uint8 [n,h,w,3] -> uint8 [n,out_h,out_w,3] with cv2.resize's
+ * uint8 INTER_LINEAR fixed-point arithmetic (what cv2.resize itself returns for a uint8 image). */
+int y4_resize_u8(const uint8_t* imgs_dev, int n, int h, int w, uint8_t* out_dev, int out_h, int out_w, void* stream);
 /* SPP (custom_layers.py:130-134): x = buf[..., 3c:4c] -> buf[..., 0:c]=maxpool13, [c:2c]=maxpool9,
  * [2c:3c]=maxpool5 (stride 1, 'same'), buf is [n,side,side,4c] */
 int y4_spp(int dtype, void* buf_dev, int n, int side, int c, void* stream);

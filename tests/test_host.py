@@ -118,3 +118,20 @@ def test_config_mirror():
     assert len(yolo_config['anchors']) == 18 and yolo_config['xyscale'] == [1.2, 1.1, 1.05]
     c = make_config(608)
     assert c['img_size'] == (608, 608, 3) and yolo_config['img_size'] == (416, 416, 3)
+
+
+def test_uint8_to_unit_formulas_are_exact_for_all_256_values():
+    """csrc/stem_common.h: unit_from_u8.  The reference computes `img / 255.` in float64 and Keras casts to float32
+    (models.py:95-98).  On the device the stem applies it per byte: float(v) * (1/255f) for the 16-bit dtypes (equal
+    after bf16 / fp16 rounding for every v) and one Newton step more for float32 (equal in float32 for every v)."""
+    from helpers import bf16_round
+    v = np.arange(256)
+    ref = (v.astype(np.float64) / 255.).astype(np.float32)
+    r = np.float32(1.0 / 255.0)
+    q = (v.astype(np.float32) * r).astype(np.float32)
+    assert (q != ref).sum() > 0                                   # the plain product is NOT exact in float32 ...
+    assert np.array_equal(bf16_round(q), bf16_round(ref))         # ... but it is after the 16-bit rounding
+    assert np.array_equal(q.astype(np.float16), ref.astype(np.float16))
+    e = (v.astype(np.float64) - 255.0 * q.astype(np.float64)).astype(np.float32)      # fma(-255, q, v): exact in float64
+    q2 = (q.astype(np.float64) + e.astype(np.float64) * np.float64(r)).astype(np.float32)
+    assert np.array_equal(q2, ref)

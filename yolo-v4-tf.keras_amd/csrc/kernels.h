@@ -39,8 +39,9 @@ int conv_pick_tile(int dtype, int M, int cin, int cout);
 int pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw, void* packed, hipStream_t stream);
 
 // misc_kernels.hip
-int stem_conv_launch(int dtype, const float* imgs, int n, int h, int w, const float* wk, const float* scale,
+int stem_conv_launch(int dtype, const void* imgs, int img_u8, int n, int h, int w, const float* wk, const float* scale,
                      const float* shift, int cout, int act, void* out, int out_cstride, int out_coff, hipStream_t stream);
+int resize_u8_launch(const uint8_t* img, int n, int h, int w, uint8_t* out, int H, int W, hipStream_t stream);
 int pack_stem_weights(const float* w_oihw, float* wk, int cout, hipStream_t stream);
 int preprocess_u8_launch(const uint8_t* img, int h, int w, float* out, int H, int W, hipStream_t stream);
 int spp_launch(int dtype, void* buf, int n, int side, int c, hipStream_t stream);
@@ -51,7 +52,7 @@ int fold_bn_launch(const float* rec, float* scale, float* shift, int cout, int c
 
 // stem_down.hip: convs 0+1 fused (16-bit dtypes), c0 stays in LDS
 bool stem_down_supported(int dtype, int S);
-int stem_down_launch(int dtype, const float* imgs, int n, int S, const void* stem_wk, const float* s0_scale,
+int stem_down_launch(int dtype, const void* imgs, int img_u8, int n, int S, const void* stem_wk, const float* s0_scale,
                      const float* s0_shift, int act0, const void* w1_packed, const float* s1_scale, const float* s1_shift,
                      int act1, void* out, int out_cstride, int out_coff, hipStream_t stream);
 

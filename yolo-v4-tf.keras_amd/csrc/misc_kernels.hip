@@ -15,8 +15,8 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 // addresses from a [27][COUT] float table, so they arrive as scalar loads (s_load_dwordx16) and feed
 // v_fma as SGPR operands: no LDS, no per-lane weight registers.  HBM-bound by design: reads 12 B/pixel
 // (fp32 RGB, L1-shared between neighbours), writes COUT*sizeof(T) per pixel, fully coalesced.
-template <int DT, int COUT>
-__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ wk,
+template <int DT, int COUT, class IMG>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const IMG* __restrict__ img, const float* __restrict__ wk,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         typename Elem<DT>::type* __restrict__ out, int N, int H, int W,
                                                         int out_cstride, int out_coff, int act) {
@@ -35,15 +35,15 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     for (int ky = 0; ky < 3; ++ky) {
         const int yy = y + ky - 1;
         const bool oky = (unsigned)yy < (unsigned)H;
-        const float* row = img + (((int64_t)n * H + (oky ? yy : 0)) * W) * 3;
+        const IMG* row = img + (((int64_t)n * H + (oky ? yy : 0)) * W) * 3;
         float v[9];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int xx = x + kx - 1;
             const bool ok = oky && (unsigned)xx < (unsigned)W;
-            const float* ip = row + (ok ? xx : 0) * 3;
+            const IMG* ip = row + (ok ? xx : 0) * 3;
 #pragma unroll
-            for (int ci = 0; ci < 3; ++ci) v[kx * 3 + ci] = ok ? ip[ci] : 0.f;
+            for (int ci = 0; ci < 3; ++ci) v[kx * 3 + ci] = ok ? img_elem<DT == Y4_F32>(ip + ci) : 0.f;
         }
         const float* wrow = wk + ky * 9 * COUT;        // wave-uniform -> scalar loads
 #pragma unroll
@@ -73,8 +73,8 @@ typedef __attribute__((ext_vector_type(4))) float stem_f32x4;
 typedef __attribute__((ext_vector_type(8))) short stem_bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 stem_f16x8;
 
-template <int DT>
-__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ img, const u32x4* __restrict__ wfrag,
+template <int DT, class IMG>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const IMG* __restrict__ img, const u32x4* __restrict__ wfrag,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         typename Elem<DT>::type* __restrict__ out, int N, int H, int W,
                                                         int out_cstride, int out_coff, int act, FastDiv div_hw,
@@ -102,10 +102,10 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         // wave-uniform: the 16 pixels are one run of a row (W % 16 == 0) away from the image border
         const int y0 = __builtin_amdgcn_readfirstlane(y), x0 = __builtin_amdgcn_readfirstlane(x);
         const bool interior = tile_rows && p0 + 16 <= total && y0 >= 1 && y0 <= H - 2 && x0 >= 1 && x0 + 16 <= W - 1;
-        const float* imgn = img + (int64_t)n * HW * 3;
+        const IMG* imgn = img + (int64_t)n * HW * 3;
         float v[8];
-        if (interior) stem_gather<false>(imgn, y, x, H, W, g, v);
-        else stem_gather<true>(imgn, y, x, H, W, g, v);
+        if (interior) stem_gather<false, false, IMG>(imgn, y, x, H, W, g, v);
+        else stem_gather<true, false, IMG>(imgn, y, x, H, W, g, v);
         u32x4 xf;
         E::store_chunk(&xf, v);
         stem_f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -165,32 +165,40 @@ int pack_stem_weights(const float* w_oihw, float* wk, int cout, hipStream_t stre
     return Y4_OK;
 }
 
-int stem_conv_launch(int dtype, const float* imgs, int n, int h, int w, const float* wk, const float* scale,
-                     const float* shift, int cout, int act, void* out, int out_cstride, int out_coff,
-                     hipStream_t stream) {
-    Y4_REQUIRE(cout == 32, Y4_EINVAL, "stem_conv: cout %d (the plan's stem has 32 filters)", cout);
-    Y4_REQUIRE(imgs && wk && scale && shift && out, Y4_EINVAL, "stem_conv: null pointer");
-    const int epc = 16 / elem_size(dtype);
-    Y4_REQUIRE(out_cstride % epc == 0 && out_coff % epc == 0, Y4_EINVAL, "stem_conv: output view not 16-byte aligned");
+template <class IMG>
+static int stem_conv_launch_t(int dtype, const IMG* imgs, int n, int h, int w, const float* wk, const float* scale,
+                              const float* shift, int act, void* out, int out_cstride, int out_coff, hipStream_t stream) {
     const int64_t total = (int64_t)n * h * w;
-    Y4_REQUIRE(total * 3 < (1ll << 31), Y4_EINVAL, "stem_conv: image batch too large");
     if (dtype == Y4_F32) {
-        hipLaunchKernelGGL((stem_conv_kernel<Y4_F32, 32>), dim3((int)((total + 255) / 256)), dim3(256), 0, stream, imgs, wk, scale, shift,
+        hipLaunchKernelGGL((stem_conv_kernel<Y4_F32, 32, IMG>), dim3((int)((total + 255) / 256)), dim3(256), 0, stream, imgs, wk, scale, shift,
                            (float*)out, n, h, w, out_cstride, out_coff, act);
     } else {
         const int tpw = 8;                                        // 16-pixel tiles per wave
         const int blocks = (int)((total + 4 * tpw * 16 - 1) / (4 * tpw * 16));
         const FastDiv dhw = fastdiv_make((uint32_t)(h * w)), dw = fastdiv_make((uint32_t)w);
         if (dtype == Y4_BF16)
-            hipLaunchKernelGGL(stem_mfma_kernel<Y4_BF16>, dim3(blocks), dim3(256), 0, stream, imgs, (const u32x4*)((const char*)wk + 4096),
+            hipLaunchKernelGGL((stem_mfma_kernel<Y4_BF16, IMG>), dim3(blocks), dim3(256), 0, stream, imgs, (const u32x4*)((const char*)wk + 4096),
                                scale, shift, (uint16_t*)out, n, h, w, out_cstride, out_coff, act, dhw, dw, tpw);
         else if (dtype == Y4_F16)
-            hipLaunchKernelGGL(stem_mfma_kernel<Y4_F16>, dim3(blocks), dim3(256), 0, stream, imgs, (const u32x4*)((const char*)wk + 6144),
+            hipLaunchKernelGGL((stem_mfma_kernel<Y4_F16, IMG>), dim3(blocks), dim3(256), 0, stream, imgs, (const u32x4*)((const char*)wk + 6144),
                                scale, shift, (_Float16*)out, n, h, w, out_cstride, out_coff, act, dhw, dw, tpw);
         else { set_error("stem_conv: bad dtype %d", dtype); return Y4_EINVAL; }
     }
     Y4_CHECK_HIP(hipGetLastError());
     return Y4_OK;
+}
+
+// imgs: float32 [n,h,w,3] in [0,1], or (img_u8) uint8 [n,h,w,3] before the /255 (applied on the fly, stem_common.h)
+int stem_conv_launch(int dtype, const void* imgs, int img_u8, int n, int h, int w, const float* wk, const float* scale,
+                     const float* shift, int cout, int act, void* out, int out_cstride, int out_coff,
+                     hipStream_t stream) {
+    Y4_REQUIRE(cout == 32, Y4_EINVAL, "stem_conv: cout %d (the plan's stem has 32 filters)", cout);
+    Y4_REQUIRE(imgs && wk && scale && shift && out, Y4_EINVAL, "stem_conv: null pointer");
+    const int epc = 16 / elem_size(dtype);
+    Y4_REQUIRE(out_cstride % epc == 0 && out_coff % epc == 0, Y4_EINVAL, "stem_conv: output view not 16-byte aligned");
+    Y4_REQUIRE((int64_t)n * h * w * 3 < (1ll << 31), Y4_EINVAL, "stem_conv: image batch too large");
+    if (img_u8) return stem_conv_launch_t(dtype, (const uint8_t*)imgs, n, h, w, wk, scale, shift, act, out, out_cstride, out_coff, stream);
+    return stem_conv_launch_t(dtype, (const float*)imgs, n, h, w, wk, scale, shift, act, out, out_cstride, out_coff, stream);
 }
 
 // ------------------------------------------------------------------------------------------- SPP
@@ -401,6 +409,42 @@ __global__ void preprocess_u8_kernel(const uint8_t* __restrict__ img, int h, int
         }
         out[i * 3 + c] = (float)((double)v / 255.0);
     }
+}
+
+// The resize half alone, batched: uint8 [n,h,w,3] -> uint8 [n,H,W,3] (cv2.resize's own output type); the `/ 255.` then
+// happens inside the stem's operand load (y4_forward_u8), so no float image tensor exists at all.
+__global__ void resize_u8_kernel(const uint8_t* __restrict__ img, int n, int h, int w, uint8_t* __restrict__ out, int H, int W) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * H * W) return;
+    const int b = (int)(i / (H * W)), r = (int)(i - (int64_t)b * H * W);
+    const int y = r / W, x = r - y * W;
+    const uint8_t* src = img + (int64_t)b * h * w * 3;
+    int x0, x1, ax0, ax1, y0, y1, ay0, ay1;
+    lin_coeff(x, W, w, x0, x1, ax0, ax1);
+    lin_coeff(y, H, h, y0, y1, ay0, ay1);
+    const bool same = (h == H && w == W);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int v;
+        if (same) {
+            v = src[(y * w + x) * 3 + c];
+        } else {
+            const int top = src[(y0 * w + x0) * 3 + c] * ax0 + src[(y0 * w + x1) * 3 + c] * ax1;   // x2048
+            const int bot = src[(y1 * w + x0) * 3 + c] * ax0 + src[(y1 * w + x1) * 3 + c] * ax1;
+            v = (((ay0 * (top >> 4)) >> 16) + ((ay1 * (bot >> 4)) >> 16) + 2) >> 2;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        out[i * 3 + c] = (uint8_t)v;
+    }
+}
+
+int resize_u8_launch(const uint8_t* img, int n, int h, int w, uint8_t* out, int H, int W, hipStream_t stream) {
+    Y4_REQUIRE(img && out && n > 0 && h > 0 && w > 0 && H > 0 && W > 0, Y4_EINVAL, "resize_u8: bad argument");
+    Y4_REQUIRE((int64_t)n * h * w * 3 < (1ll << 31) && (int64_t)n * H * W * 3 < (1ll << 31), Y4_EINVAL, "resize_u8: batch too large");
+    const int64_t total = (int64_t)n * H * W;
+    hipLaunchKernelGGL(resize_u8_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, img, n, h, w, out, H, W);
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
 }
 
 int preprocess_u8_launch(const uint8_t* img, int h, int w, float* out, int H, int W, hipStream_t stream) {

@@ -111,6 +111,8 @@ struct y4_ctx {
     size_t stage_blob_off = 0;
     bool stage_on = false, stage_enabled = true;
     bool stage_active() const { return stage_first >= 0 && stage_on && stage_enabled; }
+    // images of the current call are uint8 frames at network size (y4_forward_u8 / y4_predict_u8): the stem divides by 255
+    bool img_u8 = false;
 };
 
 namespace {
@@ -434,6 +436,12 @@ char* buf_ptr(y4_handle h, const View& v, int img0 = 0) {
     return h->act + b.offset + (size_t)img0 * b.side * b.side * b.channels * (b.f32 ? 4 : h->es);
 }
 
+// image `img0` of the caller's batch (float32 or uint8 elements, see y4_ctx::img_u8)
+const void* img_at(y4_handle h, const void* imgs, int img0) {
+    if (!imgs) return imgs;
+    return (const char*)imgs + (size_t)img0 * h->S * h->S * 3 * (h->img_u8 ? 1 : 4);
+}
+
 struct Launch {
     int op, img0, cnt;
 };
@@ -450,7 +458,7 @@ void build_schedule(y4_handle h, int n, std::vector<Launch>& out) {
     for (int i = first_full; i < nops; ++i) out.push_back({i, 0, n});
 }
 
-int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s, int img0 = 0, bool allow_chain = true) {
+int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, int img0 = 0, bool allow_chain = true) {
     if (op.kind == OP_SPP) return spp_launch(h->cfg.dtype, buf_ptr(h, op.in, img0), n, op.in.side, op.in.cstride / 4, s);
     const Layer& L = h->layers[op.conv];
     const float* scale = (const float*)(h->wts + L.scale_off);
@@ -458,7 +466,7 @@ int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s, i
     if (op.kind == OP_STEM && h->fuse_stem) {
         const Op& o1 = h->ops[1];
         const Layer& L1 = h->layers[1];
-        return stem_down_launch(h->cfg.dtype, imgs ? imgs + (size_t)img0 * h->S * h->S * 3 : imgs, n, h->S,
+        return stem_down_launch(h->cfg.dtype, img_at(h, imgs, img0), h->img_u8 ? 1 : 0, n, h->S,
                                 h->wts + L.w_off, scale, shift, L.d.act, h->wts + L1.w_off,
                                 (const float*)(h->wts + L1.scale_off), (const float*)(h->wts + L1.shift_off), L1.d.act,
                                 buf_ptr(h, o1.out, img0), o1.out.cstride, o1.out.coff, s);
@@ -489,7 +497,7 @@ int run_op(y4_handle h, const Op& op, const float* imgs, int n, hipStream_t s, i
             else if (&h->ops[ch.tail[0]] == &op || (ch.tail[1] >= 0 && &h->ops[ch.tail[1]] == &op)) return Y4_OK;   // ran with its head
         }
     if (op.kind == OP_STEM)
-        return stem_conv_launch(h->cfg.dtype, imgs ? imgs + (size_t)img0 * h->S * h->S * 3 : imgs, n, h->S, h->S,
+        return stem_conv_launch(h->cfg.dtype, img_at(h, imgs, img0), h->img_u8 ? 1 : 0, n, h->S, h->S,
                                 (const float*)(h->wts + L.w_off), scale, shift, L.d.cout, L.d.act,
                                 buf_ptr(h, op.out, img0), op.out.cstride, op.out.coff, s);
     {
@@ -728,15 +736,21 @@ int y4_adopt_packed_weights(y4_handle h) {
     return Y4_OK;
 }
 
-int y4_forward(y4_handle h, const float* imgs, int n, void* stream) {
+static int forward_impl(y4_handle h, const void* imgs, bool u8, int n, void* stream) {
     if (int r = check_ready(h, n)) return r;
     Y4_REQUIRE(imgs, Y4_EINVAL, "y4_forward: null images");
+    h->img_u8 = u8;
     std::vector<Launch> sched;
     build_schedule(h, n, sched);
+    int rc = Y4_OK;
     for (const Launch& l : sched)
-        if (int r = run_op(h, h->ops[l.op], imgs, l.cnt, (hipStream_t)stream, l.img0)) return r;
-    return Y4_OK;
+        if ((rc = run_op(h, h->ops[l.op], imgs, l.cnt, (hipStream_t)stream, l.img0))) break;
+    h->img_u8 = false;
+    return rc;
 }
+
+int y4_forward(y4_handle h, const float* imgs, int n, void* stream) { return forward_impl(h, imgs, false, n, stream); }
+int y4_forward_u8(y4_handle h, const uint8_t* imgs, int n, void* stream) { return forward_impl(h, imgs, true, n, stream); }
 
 int y4_get_heads(y4_handle h, int n, float* out_s, float* out_m, float* out_l, void* stream) {
     if (int r = check_ready(h, n)) return r;
@@ -795,7 +809,7 @@ int y4_decode_nms(y4_handle h, int n, float iou_threshold, float score_threshold
 }
 
 // forward + decode + NMS; when `ev` is given, ev[0] is recorded before the first op and ev[i+1] after op i
-static int predict_impl(y4_handle h, const float* imgs, int n, float* boxes, float* scores, float* classes,
+static int predict_impl(y4_handle h, const void* imgs, int n, float* boxes, float* scores, float* classes,
                         int32_t* valid, int32_t* kept_idx, hipStream_t s, hipEvent_t* ev) {
     if (int r = check_ready(h, n)) return r;
     Y4_REQUIRE(imgs && boxes && scores && classes && valid, Y4_EINVAL, "y4_predict: null argument");
@@ -840,14 +854,25 @@ static int predict_impl(y4_handle h, const float* imgs, int n, float* boxes, flo
     return Y4_OK;
 }
 
-int y4_predict(y4_handle h, const float* imgs, int n, float* boxes, float* scores, float* classes, int32_t* valid,
-               int32_t* kept_idx, void* stream) {
+static int predict_any(y4_handle h, const void* imgs, bool u8, int n, float* boxes, float* scores, float* classes, int32_t* valid,
+                       int32_t* kept_idx, void* stream) {
     if (int r = check_handle(h)) return r;
     hipEvent_t* ev = nullptr;
     if (h->t_max_steps > 0 && h->t_steps < h->t_max_steps) ev = h->t_events.data() + (size_t)h->t_steps * h->t_per_step;
+    h->img_u8 = u8;
     const int rc = predict_impl(h, imgs, n, boxes, scores, classes, valid, kept_idx, (hipStream_t)stream, ev);
+    h->img_u8 = false;
     if (ev && rc == Y4_OK && h->t_recorded_this_call) ++h->t_steps;
     return rc;
+}
+
+int y4_predict(y4_handle h, const float* imgs, int n, float* boxes, float* scores, float* classes, int32_t* valid,
+               int32_t* kept_idx, void* stream) {
+    return predict_any(h, imgs, false, n, boxes, scores, classes, valid, kept_idx, stream);
+}
+int y4_predict_u8(y4_handle h, const uint8_t* imgs, int n, float* boxes, float* scores, float* classes, int32_t* valid,
+                  int32_t* kept_idx, void* stream) {
+    return predict_any(h, imgs, true, n, boxes, scores, classes, valid, kept_idx, stream);
 }
 
 // Per-layer tile choice by measurement: every tile configuration that fits a conv is timed on the layer's
@@ -1189,8 +1214,12 @@ int y4_pack_stem_weights(const float* w_oihw_dev, float* wk_dev, int cout, void*
 
 int y4_stem_conv(int dtype, const float* imgs_dev, int n, int h, int w, const float* wk_dev, const float* scale,
                  const float* shift, int cout, int act, void* out_dev, int out_cstride, int out_coff, void* stream) {
-    return stem_conv_launch(dtype, imgs_dev, n, h, w, wk_dev, scale, shift, cout, act, out_dev, out_cstride,
+    return stem_conv_launch(dtype, imgs_dev, 0, n, h, w, wk_dev, scale, shift, cout, act, out_dev, out_cstride,
                             out_coff, (hipStream_t)stream);
+}
+
+int y4_resize_u8(const uint8_t* imgs_dev, int n, int h, int w, uint8_t* out_dev, int out_h, int out_w, void* stream) {
+    return resize_u8_launch(imgs_dev, n, h, w, out_dev, out_h, out_w, (hipStream_t)stream);
 }
 
 int y4_preprocess_u8(const uint8_t* img_dev, int h, int w, float* out_dev, int out_h, int out_w, void* stream) {

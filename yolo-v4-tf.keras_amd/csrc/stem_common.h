@@ -17,21 +17,45 @@ __host__ __device__ inline void stem_k_slot(int g, int e, int& ky, int& j) {
     else { ky = -1; j = 0; }
 }
 
-// This lane's 8 K values for pixel (y, x) of the image at `img` (H x W x 3 floats).
+// ---- image element types.  float: the preprocessed tensor of `Yolov4.preprocess_img` (reference models.py:95-98).
+// uint8_t: a frame already at network size, BEFORE the `/ 255.`; the stem then applies it on the fly:
+//   16-bit dtypes: float(v) * (1/255f), whose bf16 / fp16 rounding equals that of float(double(v)/255.) for all 256 values;
+//   float32      : one Newton step on top, q' = fma(fma(-255, q, v), 1/255f, q), which equals float(double(v)/255.) for
+//                  all 256 values (both checked exhaustively: tests/test_host.py, tests/test_gpu_api.py).
+template <bool EXACT32>
+__device__ __forceinline__ float unit_from_u8(uint32_t v) {
+    const float f = (float)v, r = 1.0f / 255.0f;
+    const float q = f * r;
+    if (!EXACT32) return q;
+    return fmaf(fmaf(-255.0f, q, f), r, q);
+}
+template <bool EXACT32> __device__ __forceinline__ float img_elem(const float* p) { return *p; }
+template <bool EXACT32> __device__ __forceinline__ float img_elem(const uint8_t* p) { return unit_from_u8<EXACT32>(*p); }
+// 8 consecutive elements starting at p (no alignment beyond the element's own)
+template <bool EXACT32> __device__ __forceinline__ void img_run8(const float* p, float v[8]) {
+    f32x4_t a, b;
+    __builtin_memcpy(&a, p, 16);
+    __builtin_memcpy(&b, p + 4, 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+template <bool EXACT32> __device__ __forceinline__ void img_run8(const uint8_t* p, float v[8]) {
+    uint32_t w[2];
+    __builtin_memcpy(w, p, 8);                       // one (unaligned) global_load_dwordx2
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = unit_from_u8<EXACT32>((w[e >> 2] >> (8 * (e & 3))) & 0xffu);
+}
+
+// This lane's 8 K values for pixel (y, x) of the image at `img` (H x W x 3 elements).
 // EDGE = false: rows y-1..y+1 and columns x-1..x+1 are inside the image for every lane of the wave.
-template <bool EDGE>
-__device__ __forceinline__ void stem_gather(const float* __restrict__ img, int y, int x, int H, int W, int g, float v[8]) {
+template <bool EDGE, bool EXACT32 = false, class IMG = float>
+__device__ __forceinline__ void stem_gather(const IMG* __restrict__ img, int y, int x, int H, int W, int g, float v[8]) {
     if (!EDGE) {
         if (g < 3) {
-            const float* p = img + ((y + g - 1) * W + x - 1) * 3;
-            f32x4_t a, b;
-            __builtin_memcpy(&a, p, 16);
-            __builtin_memcpy(&b, p + 4, 16);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+            img_run8<EXACT32>(img + ((y + g - 1) * W + x - 1) * 3, v);
         } else {
-            const float* p = img + ((y - 1) * W + x + 1) * 3 + 2;
-            v[0] = p[0]; v[1] = p[W * 3]; v[2] = p[2 * W * 3];
+            const IMG* p = img + ((y - 1) * W + x + 1) * 3 + 2;
+            v[0] = img_elem<EXACT32>(p); v[1] = img_elem<EXACT32>(p + W * 3); v[2] = img_elem<EXACT32>(p + 2 * W * 3);
 #pragma unroll
             for (int e = 3; e < 8; ++e) v[e] = 0.f;
         }
@@ -43,7 +67,7 @@ __device__ __forceinline__ void stem_gather(const float* __restrict__ img, int y
             const int kx = j / 3, ci = j - kx * 3;
             const int yy = y + ky - 1, xx = x + kx - 1;
             const bool ok = ky >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-            v[e] = ok ? img[(yy * W + xx) * 3 + ci] : 0.f;
+            v[e] = ok ? img_elem<EXACT32>(img + (yy * W + xx) * 3 + ci) : 0.f;
         }
     }
 }

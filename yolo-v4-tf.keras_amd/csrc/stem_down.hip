@@ -18,7 +18,7 @@
 namespace y4 {
 
 struct StemDownK {
-    const float* img;            // [N, S, S, 3] float32
+    const void* img;             // [N, S, S, 3] float32 in [0,1], or uint8 before the /255 (template IMG)
     const u32x4* stem_frag;      // [2][64] 16-byte weight fragments of the stem (see pack_stem_kernel)
     const float* s0_scale;       // [32]
     const float* s0_shift;
@@ -37,7 +37,7 @@ constexpr int SD_UNROLL = 4;                            // stem tiles whose gath
 
 static __device__ __forceinline__ int sd_swz(int row) { return (row >> 1) & 3; }
 
-template <int DT, int MFW>     // MFW = max pixel fragments per wave row: ceil((Wo/16) / SD_WM)
+template <int DT, int MFW, class IMG>     // MFW = max pixel fragments per wave row: ceil((Wo/16) / SD_WM)
 __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDownK p) {
     using E = Elem<DT>;
     using T = typename E::type;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
         for (int c = 0; c < 8; ++c) { sc[c] = p.s0_scale[g * 8 + c]; sh[c] = p.s0_shift[g * 8 + c]; }
         const int tiles_per_row = S >> 4;
         const int ntiles = 3 * tiles_per_row;
-        const float* const img_n = p.img + (int64_t)n * S * S * 3;
+        const IMG* const img_n = (const IMG*)p.img + (int64_t)n * S * S * 3;
         // this lane's share of a pixel's patch, relative to the tile's first pixel (stem_common.h): groups 0..2 read
         // floats 0..7 of row y+g-1's run, group 3 float 8 of the three runs
         const int lane_off = g < 3 ? ((g - 1) * S + q - 1) * 3 : (-S + q + 1) * 3 + 2;
@@ -113,19 +113,13 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
                 // the epilogues, so that neither the load nor the MFMA latency is paid per tile
                 if (g < 3) {
 #pragma unroll
-                    for (int u = 0; u < SD_UNROLL; ++u) {
-                        const float* pp = img_n + (lane_off + (ys[u] * S + xts[u] * 16) * 3);
-                        f32x4 a, b;
-                        __builtin_memcpy(&a, pp, 16);
-                        __builtin_memcpy(&b, pp + 4, 16);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[u][e] = a[e]; v[u][4 + e] = b[e]; }
-                    }
+                    for (int u = 0; u < SD_UNROLL; ++u)
+                        img_run8<false>(img_n + (lane_off + (ys[u] * S + xts[u] * 16) * 3), v[u]);
                 } else {
 #pragma unroll
                     for (int u = 0; u < SD_UNROLL; ++u) {
-                        const float* pp = img_n + (lane_off + (ys[u] * S + xts[u] * 16) * 3);
-                        v[u][0] = pp[0]; v[u][1] = pp[S * 3]; v[u][2] = pp[2 * S * 3];
+                        const IMG* pp = img_n + (lane_off + (ys[u] * S + xts[u] * 16) * 3);
+                        v[u][0] = img_elem<false>(pp); v[u][1] = img_elem<false>(pp + S * 3); v[u][2] = img_elem<false>(pp + 2 * S * 3);
 #pragma unroll
                         for (int e = 3; e < 8; ++e) v[u][e] = 0.f;
                     }
@@ -159,7 +153,7 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
                 for (int u = 0; u < SD_UNROLL; ++u) {
                     u32x4 packed = u32x4{0u, 0u, 0u, 0u};     // c0 rows outside the image are the conv's zero padding
                     if (!(rys[u] & 4)) {
-                        stem_gather<true>(img_n, ys[u], xs[u], S, S, g, v[u]);
+                        stem_gather<true, false, IMG>(img_n, ys[u], xs[u], S, S, g, v[u]);
                         u32x4 xf;
                         E::store_chunk(&xf, v[u]);
                         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -240,7 +234,7 @@ bool stem_down_supported(int dtype, int S) {
     return dtype != Y4_F32 && S % 32 == 0 && stem_down_lds_bytes(S) <= 160 * 1024 && (S / 32 + SD_WM - 1) / SD_WM <= 3;
 }
 
-template <int DT>
+template <int DT, class IMG>
 static int stem_down_dispatch(const StemDownK& k, hipStream_t stream) {
     const int mfw = (k.S / 32 + SD_WM - 1) / SD_WM;         // ceil((Wo/16) / SD_WM)
     const size_t lds = stem_down_lds_bytes(k.S);
@@ -249,11 +243,11 @@ static int stem_down_dispatch(const StemDownK& k, hipStream_t stream) {
     case M: {                                                                                                \
         static PerDeviceOnce once;                                                                           \
         if (const uint64_t bit = once.due()) {                                                               \
-            Y4_CHECK_HIP(hipFuncSetAttribute((const void*)stem_down_kernel<DT, M>,                          \
+            Y4_CHECK_HIP(hipFuncSetAttribute((const void*)stem_down_kernel<DT, M, IMG>,                     \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));       \
             once.mark(bit);                                                                                  \
         }                                                                                                    \
-        hipLaunchKernelGGL((stem_down_kernel<DT, M>), dim3(blocks), dim3(64 * SD_WAVES), lds, stream, k);              \
+        hipLaunchKernelGGL((stem_down_kernel<DT, M, IMG>), dim3(blocks), dim3(64 * SD_WAVES), lds, stream, k);         \
         break;                                                                                               \
     }
     switch (mfw) {
@@ -264,7 +258,7 @@ static int stem_down_dispatch(const StemDownK& k, hipStream_t stream) {
     return Y4_OK;
 }
 
-int stem_down_launch(int dtype, const float* imgs, int n, int S, const void* stem_wk, const float* s0_scale,
+int stem_down_launch(int dtype, const void* imgs, int img_u8, int n, int S, const void* stem_wk, const float* s0_scale,
                      const float* s0_shift, int act0, const void* w1_packed, const float* s1_scale, const float* s1_shift,
                      int act1, void* out, int out_cstride, int out_coff, hipStream_t stream) {
     Y4_REQUIRE(stem_down_supported(dtype, S), Y4_EINVAL, "stem_down: dtype %d / image side %d not supported", dtype, S);
@@ -280,7 +274,8 @@ int stem_down_launch(int dtype, const float* imgs, int n, int S, const void* ste
     k.w1_bytes = (unsigned)(round_up(64, COUT_PAD) * 9 * 32 * 2);
     k.out = (char*)out; k.out_cstride = out_cstride; k.out_coff = out_coff;
     k.N = n; k.S = S;
-    return dtype == Y4_BF16 ? stem_down_dispatch<Y4_BF16>(k, stream) : stem_down_dispatch<Y4_F16>(k, stream);
+    if (img_u8) return dtype == Y4_BF16 ? stem_down_dispatch<Y4_BF16, uint8_t>(k, stream) : stem_down_dispatch<Y4_F16, uint8_t>(k, stream);
+    return dtype == Y4_BF16 ? stem_down_dispatch<Y4_BF16, float>(k, stream) : stem_down_dispatch<Y4_F16, float>(k, stream);
 }
 
 }  // namespace y4

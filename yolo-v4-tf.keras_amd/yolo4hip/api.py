@@ -7,9 +7,12 @@ weight_path, max_boxes`), `.yolo_model.predict(imgs)` -> 3 raw heads, `.inferenc
 with their prints (`img shape:`, `# of bboxes:`) and DataFrame layout.
 Differences, all supersets: the passed `config` is honoured (the reference reads the module global,
 models.py:26-37); grid sizes follow img_size (the reference hard-codes 52/26/13); extra keyword-only
-arguments pick the compute dtype / batch capacity.  Training (`fit`, `training_model`), Keras
-save/load and the mAP tooling are out of scope for this inference framework and raise.
+arguments pick the compute dtype / batch capacity.  `save_model` / `load_model` (models.py:86-93) are stand-ins on a
+self-describing checkpoint of this framework (Keras' SavedModel / H5 needs TensorFlow); `eval_map` (models.py:182-507)
+is the VOC mAP tool over the exported text files (yolo4hip/evalmap.py).  Training (`fit`, `training_model`) is out of
+scope for this inference framework and raises.
 """
+import json
 import os
 
 import numpy as np
@@ -72,15 +75,59 @@ class Yolov4(object):
             print(f'load from {self.weight_path}')
         else:
             # the reference leaves Keras' random initialisation in place; ours is the seeded synthetic set
-            self.engine.load_weight_blob(W.flatten(W.synth_weights(self.plan, self._synth_seed)))
+            self._set_weights(W.flatten(W.synth_weights(self.plan, self._synth_seed)))
 
-    # ---- out of scope (training / Keras checkpoints)
-    def load_model(self, path):
-        raise NotImplementedError('Keras SavedModel/H5 checkpoints need TensorFlow; load Darknet .weights instead')
+    def _set_weights(self, flat):
+        """flat: the Darknet-order float32 stream (weights.flatten).  Kept on the host like Keras keeps its variables,
+        so that `save_model` can write it back."""
+        self._flat = np.ascontiguousarray(flat, dtype=np.float32)
+        self.engine.load_weight_blob(self._flat)
+
+    # ---- reference models.py:86-93.  Keras writes architecture + variables of `yolo_model` (SavedModel / H5); without
+    # TensorFlow the stand-in is a self-describing checkpoint of THIS framework: magic, a JSON header (what fixes the
+    # architecture here: img_size, num_classes, anchors, strides, xyscale), then the float32 weight stream in Darknet
+    # order -- dtype independent, so a model saved from a bf16 engine loads into an fp32 one.  A path ending in
+    # `.weights` is written / read as a plain Darknet file instead.
+    _CKPT_MAGIC = b'Y4CKPT1\n'
 
     def save_model(self, path):
-        raise NotImplementedError('Keras SavedModel/H5 checkpoints need TensorFlow')
+        if path.endswith('.weights'):
+            W.write_darknet(path, W.unflatten(self.plan, self._flat))
+            return
+        head = json.dumps({'format': 'yolo4hip-checkpoint', 'version': 1, 'img_size': list(self.img_size),
+                           'num_classes': self.num_classes, 'class_names': self.class_names,
+                           'anchors': np.asarray(self.anchors).reshape(-1).tolist(), 'strides': list(self.strides),
+                           'xyscale': list(self.xyscale), 'n_floats': int(self._flat.size)}).encode()
+        with open(path, 'wb') as fh:
+            fh.write(self._CKPT_MAGIC)
+            fh.write(len(head).to_bytes(8, 'little'))
+            fh.write(head)
+            self._flat.tofile(fh)
 
+    def load_model(self, path):
+        """Like the reference, rebuilds `yolo_model` and `inference_model` from the file; like it (models.py:90-91: `nms`
+        called without thresholds) the inference model then uses the DEFAULT thresholds iou 0.413 / score 0.3."""
+        if path.endswith('.weights'):
+            ws, _header, _unread = W.read_darknet(path, self.plan)
+            flat = W.flatten(ws)
+        else:
+            with open(path, 'rb') as fh:
+                if fh.read(len(self._CKPT_MAGIC)) != self._CKPT_MAGIC:
+                    raise ValueError(f'{path}: not a yolo4hip checkpoint (Keras SavedModel / H5 files need TensorFlow)')
+                head = json.loads(fh.read(int.from_bytes(fh.read(8), 'little')).decode())
+                flat = np.fromfile(fh, dtype=np.float32)
+            same = (head['num_classes'] == self.num_classes and list(head['img_size']) == list(self.img_size)
+                    and head['n_floats'] == self.plan.n_params)
+            if not same or flat.size != self.plan.n_params:
+                raise ValueError(f"{path}: checkpoint is for img_size {head['img_size']}, {head['num_classes']} classes, "
+                                 f"{flat.size} floats; this model has {list(self.img_size)}, {self.num_classes}, "
+                                 f"{self.plan.n_params}")
+        self._set_weights(flat)
+        self.yolo_model = _KerasLikeModel(self.engine.forward_heads, 'yolo_model')
+        self.inference_model = _KerasLikeModel(
+            lambda x: self.engine.predict(x, iou_threshold=0.413, score_threshold=0.3), 'inference_model')
+
+    # ---- out of scope (SURVEY.md section 2: training)
     def fit(self, *a, **k):
         raise NotImplementedError('training is out of scope of the MI355X inference path')
 
@@ -154,6 +201,12 @@ class Yolov4(object):
                         b = boxes[j]
                         out.write(f'{names[j]} {b_scores[k, j]} {b[0]} {b[1]} {b[2]} {b[3]}\n')
 
+    # ---- reference models.py:182-507: VOC mAP over the folders export_gt / export_prediction wrote (text outputs and
+    # prints kept, matplotlib windows not; also returns the numbers) -- see yolo4hip/evalmap.py
+    def eval_map(self, gt_folder_path, pred_folder_path, temp_json_folder_path, output_files_path):
+        from .evalmap import eval_map
+        return eval_map(gt_folder_path, pred_folder_path, temp_json_folder_path, output_files_path)
+
     # ---- reference models.py:509-514 (note: no BGR->RGB flip there; cv2.imread order is BGR)
     def predict_raw(self, img_path):
         raw_img = prepost.imread_rgb(img_path)[:, :, ::-1]
@@ -179,7 +232,7 @@ def load_weights(model, weights_file_path):
     """reference utils.py:12-53: read a Darknet `.weights` file into the model.  `model` is a `Yolov4`
     (the reference passes the Keras `yolo_model`; the facade object owns the engine here)."""
     ws, _header, unread = W.read_darknet(weights_file_path, model.plan)
-    model.engine.load_weight_blob(W.flatten(ws))
+    model._set_weights(W.flatten(ws))
     if unread == 0:
         print('all weights read')
     else:

@@ -131,9 +131,12 @@ class Engine:
 
     # ---------------------------------------------------------------- compute
     def _to_device_images(self, imgs):
-        """array-like [N,H,W,3] any float dtype (Keras casts to float32) -> contiguous cuda float32."""
+        """array-like [N,H,W,3] any float dtype (Keras casts to float32) -> contiguous cuda float32; a uint8 torch
+        tensor (frames at network size before the /255, e.g. from `preprocess_u8`) stays uint8."""
         torch = self.torch
-        if isinstance(imgs, torch.Tensor):
+        if isinstance(imgs, torch.Tensor) and imgs.dtype == torch.uint8:
+            t = imgs.to(self.device)                        # network-size uint8 frames: the stem divides by 255
+        elif isinstance(imgs, torch.Tensor):
             t = imgs.to(self.device, dtype=torch.float32)
         else:
             a = np.asarray(imgs)
@@ -144,28 +147,59 @@ class Engine:
             raise ValueError(f"expected images of shape [N,{self.img_size},{self.img_size},3], got {tuple(t.shape)}")
         return t.contiguous()
 
-    def preprocess_u8(self, raw_imgs):
-        """Device-side `Yolov4.preprocess_img` (reference models.py:95-98) for one uint8 RGB image [h,w,3] or a list
-        of them (any sizes): returns the float32 cuda tensor [n,S,S,3] that `forward_device` / `predict` take."""
+    def preprocess_u8(self, raw_imgs, as_float=False):
+        """Device-side `Yolov4.preprocess_img` (reference models.py:95-98) for one uint8 RGB image [h,w,3] or a list of
+        them (any sizes).  Returns the tensor `forward_device` / `predict` take: by default a uint8 cuda tensor [n,S,S,3]
+        (the resize done with cv2's uint8 arithmetic; the `/ 255.` then happens inside the stem's operand load), with
+        as_float=True the float32 tensor in [0,1] (`y4_preprocess_u8`).  Both give bit-identical network outputs."""
         torch = self.torch
         if isinstance(raw_imgs, np.ndarray) and raw_imgs.ndim == 3:
             raw_imgs = [raw_imgs]
-        out = torch.empty((len(raw_imgs), self.img_size, self.img_size, 3), dtype=torch.float32, device=self.device)
+        S = self.img_size
+        out = torch.empty((len(raw_imgs), S, S, 3), dtype=torch.float32 if as_float else torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
             for i, im in enumerate(raw_imgs):
                 a = np.ascontiguousarray(im)
                 if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
                     raise ValueError(f"expected uint8 [h,w,3] images, got {a.dtype} {a.shape}")
-                d = torch.from_numpy(a).to(self.device)
-                ext.check(self.lib.y4_preprocess_u8(ext.ptr(d), a.shape[0], a.shape[1], ext.ptr(out[i]), self.img_size,
-                                                    self.img_size, ext.stream_ptr()))
+                d = torch.from_numpy(a.copy() if not a.flags.writeable else a).to(self.device)
+                if as_float:
+                    ext.check(self.lib.y4_preprocess_u8(ext.ptr(d), a.shape[0], a.shape[1], ext.ptr(out[i]), S, S, ext.stream_ptr()))
+                else:
+                    ext.check(self.lib.y4_resize_u8(ext.ptr(d), 1, a.shape[0], a.shape[1], ext.ptr(out[i]), S, S, ext.stream_ptr()))
             torch.cuda.current_stream().synchronize()       # the uint8 staging tensors may be freed now
         return out
 
+    def resize_u8(self, frames_dev, out=None):
+        """Device-side `cv2.resize(img, img_size)` on a uint8 cuda batch [n,h,w,3] -> uint8 [n,S,S,3] (cv2's uint8
+        INTER_LINEAR arithmetic); frames already at network size are returned as they are."""
+        torch = self.torch
+        n, h, w, _ = frames_dev.shape
+        S = self.img_size
+        if h == S and w == S:
+            return frames_dev
+        if out is None:
+            out = torch.empty((n, S, S, 3), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            ext.check(self.lib.y4_resize_u8(ext.ptr(frames_dev), n, h, w, ext.ptr(out), S, S, ext.stream_ptr()))
+        return out[:n]
+
+    def _check_device_images(self, imgs_dev):
+        torch = self.torch
+        S = self.img_size
+        if imgs_dev.dtype not in (torch.float32, torch.uint8) or imgs_dev.dim() != 4 or tuple(imgs_dev.shape[1:]) != (S, S, 3) \
+                or not imgs_dev.is_contiguous():
+            raise ValueError(f"expected a contiguous float32 or uint8 cuda tensor [n,{S},{S},3], got {imgs_dev.dtype} {tuple(imgs_dev.shape)}")
+        return imgs_dev.dtype == torch.uint8
+
     def forward_device(self, imgs_dev):
+        """imgs_dev: float32 [n,S,S,3] in [0,1] (what preprocess_img gives), or uint8 [n,S,S,3] frames at network size
+        BEFORE the /255 -- the stem then divides inside its operand load (bit-identical, no float image tensor)."""
         n = imgs_dev.shape[0]
+        u8 = self._check_device_images(imgs_dev)
         with self.torch.cuda.device(self.device):
-            ext.check(self.lib.y4_forward(self.handle, ext.ptr(imgs_dev), n, ext.stream_ptr()))
+            fn = self.lib.y4_forward_u8 if u8 else self.lib.y4_forward
+            ext.check(fn(self.handle, ext.ptr(imgs_dev), n, ext.stream_ptr()))
 
     def heads_device(self, n):
         torch = self.torch
@@ -221,11 +255,13 @@ class Engine:
     def predict_device(self, imgs_dev, outs=None):
         """The whole hot path on device buffers: forward + decode + NMS (async on the current stream)."""
         n = imgs_dev.shape[0]
+        u8 = self._check_device_images(imgs_dev)
         outs = outs or self.alloc_outputs(n)
         b, s, c, v, k = outs
         with self.torch.cuda.device(self.device):
-            ext.check(self.lib.y4_predict(self.handle, ext.ptr(imgs_dev), n, ext.ptr(b), ext.ptr(s), ext.ptr(c),
-                                          ext.ptr(v), ext.ptr(k), ext.stream_ptr()))
+            fn = self.lib.y4_predict_u8 if u8 else self.lib.y4_predict
+            ext.check(fn(self.handle, ext.ptr(imgs_dev), n, ext.ptr(b), ext.ptr(s), ext.ptr(c),
+                         ext.ptr(v), ext.ptr(k), ext.stream_ptr()))
         return outs
 
     def _chunks(self, imgs):
@@ -260,8 +296,9 @@ class Engine:
         tensors, n <= max_batch, any h,w): yields one result list per batch, in order.  A pinned tensor is uploaded from where
         it lies and may be refilled as soon as the generator yields (its upload is waited for before every yield).  While batch i computes, batch i+1 crosses PCIe as uint8
         on a second HIP stream (pinned staging, 4x fewer bytes than float32) and batch i-1's results return to the
-        host, so the PCIe-inclusive rate approaches the device rate.  Preprocessing is `y4_preprocess_u8` (bit-identical
-        to `Yolov4.preprocess_img`, reference models.py:95-98)."""
+        host, so the PCIe-inclusive rate approaches the device rate.  No float image tensor exists: frames are resized
+        uint8 -> uint8 on the device when needed (`y4_resize_u8`) and the `/ 255.` happens inside the stem's operand load
+        (`y4_predict_u8`), bit-identical to `Yolov4.preprocess_img` (reference models.py:95-98) + float32 forward."""
         torch = self.torch
         dev = self.device
         copy_stream = torch.cuda.Stream(device=dev)        # uploads
@@ -300,7 +337,9 @@ class Engine:
                     sl["pin"] = torch.empty(shape, dtype=torch.uint8).pin_memory()
                     sl["pin_np"] = sl["pin"].numpy()
                     sl["u8"] = torch.empty(shape, dtype=torch.uint8, device=dev)
-                    sl["imgs"] = torch.empty((self.max_batch, self.img_size, self.img_size, 3), dtype=torch.float32, device=dev)
+                    # frames of another size are resized uint8 -> uint8 on the device; the /255 happens in the stem's load
+                    sl["net"] = None if shape[1:3] == (self.img_size, self.img_size) else \
+                        torch.empty((self.max_batch, self.img_size, self.img_size, 3), dtype=torch.uint8, device=dev)
                     sl["flat"] = torch.empty(int(offs[-1]), dtype=torch.int32, device=dev)
                     sl["flat_host"] = torch.empty(int(offs[-1]), dtype=torch.int32).pin_memory()
                     sl["outs"], sl["host"] = views(sl["flat"]), views(sl["flat_host"])
@@ -318,11 +357,9 @@ class Engine:
                     sl["u8"].copy_(batch if pinned_in else sl["pin"], non_blocking=True)
                     sl["up"].record(copy_stream)
                 compute.wait_event(sl["up"])
-                for i in range(n):
-                    ext.check(self.lib.y4_preprocess_u8(ext.ptr(sl["u8"][i]), a.shape[1], a.shape[2], ext.ptr(sl["imgs"][i]),
-                                                        self.img_size, self.img_size, ext.stream_ptr()))
-                sl["free"].record(compute)
-                self.predict_device(sl["imgs"][:n], tuple(t[:n] for t in sl["outs"]))
+                frames = sl["u8"] if sl["net"] is None else self.resize_u8(sl["u8"], sl["net"])
+                self.predict_device(frames[:n], tuple(t[:n] for t in sl["outs"]))
+                sl["free"].record(compute)                 # the stem has consumed the uint8 frames
                 sl["ran"].record(compute)
                 with torch.cuda.stream(down_stream):       # results leave on a third stream: compute and uploads never wait
                     down_stream.wait_event(sl["ran"])

@@ -64,11 +64,13 @@ SYMBOLS = {
     "y4_pack_weights": (_I, [_VP, _VP, C.c_size_t, _VP]),
     "y4_adopt_packed_weights": (_I, [_VP]),
     "y4_forward": (_I, [_VP, _VP, _I, _VP]),
+    "y4_forward_u8": (_I, [_VP, _VP, _I, _VP]),
     "y4_get_heads": (_I, [_VP, _I, _VP, _VP, _VP, _VP]),
     "y4_set_heads": (_I, [_VP, _I, _VP, _VP, _VP, _VP]),
     "y4_get_conv_output": (_I, [_VP, _I, _I, _VP, C.c_size_t, _VP]),
     "y4_decode_nms": (_I, [_VP, _I, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP]),
     "y4_predict": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "y4_predict_u8": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "y4_profile": (_I, [_VP, _VP, _I, _VP, _VP, _I, C.POINTER(_I), _VP]),
     "y4_autotune": (_I, [_VP, _I, _I, _VP]),
     "y4_get_tiles": (_I, [_VP, C.POINTER(C.c_int32), _I]),
@@ -88,6 +90,7 @@ SYMBOLS = {
     "y4_pack_stem_weights": (_I, [_VP, _VP, _I, _VP]),
     "y4_stem_conv": (_I, [_I, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _I, _VP]),
     "y4_preprocess_u8": (_I, [_VP, _I, _I, _VP, _I, _I, _VP]),
+    "y4_resize_u8": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _VP]),
     "y4_spp": (_I, [_I, _VP, _I, _I, _I, _VP]),
 }
 
