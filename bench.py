@@ -122,6 +122,7 @@ def parse_args(argv):
     ap.add_argument("--no-stem-fusion", action="store_true", help="run convs 0 and 1 as two kernels (c0 through HBM)")
     ap.add_argument("--no-chain-fusion", action="store_true", help="run the 3x3+Add -> 1x1 -> 1x1 runs as separate kernels")
     ap.add_argument("--no-stage-fusion", action="store_true", help="run the 304^2 CSP stage (convs 2..7) as separate kernels")
+    ap.add_argument("--no-res-fusion", action="store_true", help="run the 1x1 -> 3x3+Add residual blocks of the 64/128-channel stages as separate kernels")
     ap.add_argument("--per-op", action="store_true", help="also print the per-op time table to stderr")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / protocol self-test on CPU (gloo, no engine, no GPU work): the line says so")
@@ -205,22 +206,30 @@ def main():
     staged = False
     if args.dtype != "f32" and not args.no_stage_fusion and hasattr(eng, "set_stage_fusion"):
         staged = bool(eng.set_stage_fusion(True))  # convs 2..7 (304^2 CSP stage) as one spatially tiled kernel
+    res_mask = 0
+    if args.dtype != "f32" and not args.no_res_fusion and hasattr(eng, "set_res_fusion"):
+        eng.set_res_fusion(True)                   # residual blocks of the 64/128-channel stages as one kernel each
+        res_mask = eng.res_fusion_mask()
     if args.load_tiles:
         saved = json.load(open(args.load_tiles))
         tiles = saved["tiles"]
         eng.set_tiles(tiles)
         if staged and "stage_fusion" in saved:
             staged = bool(eng.set_stage_fusion(saved["stage_fusion"]))
+        if res_mask and "res_fusion_mask" in saved:
+            eng.set_res_fusion_mask(saved["res_fusion_mask"])
+            res_mask = eng.res_fusion_mask()
     elif not args.no_autotune:
         eng.predict_device(imgs, outs)                        # real activations in the workspace
         tiles = eng.autotune(hi - lo, reps=args.tune_reps)    # untimed, one-off: fastest tile / fusion per layer (bit-identical results)
         if staged:
             staged = bool(eng.stage_fusion_active())          # the tuner may have turned the stage kernel off
+        res_mask = eng.res_fusion_mask() if res_mask else 0
     else:
         tiles = None
     if args.save_tiles and rank == 0 and tiles:
         json.dump({"size": args.size, "classes": args.classes, "batch": args.batch, "dtype": args.dtype, "tiles": tiles,
-                   "stage_fusion": bool(staged)}, open(args.save_tiles, "w"))
+                   "stage_fusion": bool(staged), "res_fusion_mask": int(res_mask)}, open(args.save_tiles, "w"))
 
     def step():
         eng.predict_device(imgs, outs)
@@ -275,7 +284,9 @@ def main():
                          "traffic": traffic, "traffic_unit": "HBM bytes per step (all launches of the family)",
                          "traffic_source": traffic_source,
                          "kernel": "conv kernel family (convs %d..109, %d launches/step%s)" %
-                                   (first_conv, conv_launches, ", convs 2..7 in csp_stage_kernel" if staged else ""),
+                                   (first_conv, conv_launches, (", convs 2..7 in csp_stage_kernel" if staged else "") +
+                                    (", residual blocks of the %s-channel stages in resblock_kernel" %
+                                     "/".join(c for b, c in ((1, "128"), (2, "64")) if res_mask & b) if res_mask else "")),
                          "flops_per_step": conv_flops, "kernel_ms_per_step": round(conv_ms, 4),
                          "timed_steps": nrec},
             "breakdown_ms_per_step": {"conv_family": round(conv_ms, 4), ("stem_c0+c1_fused" if fused_stem else "stem_c0"): round(other.get("c0", 0.0), 4),

@@ -176,6 +176,18 @@ int y4_set_chain_fusion(y4_handle h, int on);
 int y4_set_stage_fusion(y4_handle h, int on);
 int y4_get_stage_fusion(y4_handle h);
 
+/* Scheduling knob (16-bit dtypes; results unchanged): run every residual block "1x1 conv -> 3x3 conv + Add" of the 64- and
+ * 128-channel CSP stages (reference custom_layers.py:34-44; the 152^2 and 76^2 stages at 608x608) as ONE spatially tiled
+ * kernel (csrc/resblock.hip): the halo'd 18x18-pixel tile of the block input is brought into LDS once, the 1x1 conv runs
+ * on it in place and the 3x3 conv reads all nine taps from that tile, streaming only its weights.  Bit-identical to the
+ * separate kernels.  Returns the number of such blocks (>= 0) when turned on, Y4_OK when turned off, < 0 on error.
+ * y4_autotune afterwards keeps it per channel group only where it measures faster; y4_get_res_fusion reports the groups
+ * in use as a bit mask (1: 128 channels, 2: 64 channels) and y4_set_res_fusion_mask restores such a choice.  While a
+ * block runs fused, y4_get_conv_output of its 1x1 conv fails with Y4_ESTATE (not materialised). */
+int y4_set_res_fusion(y4_handle h, int on);
+int y4_get_res_fusion(y4_handle h);
+int y4_set_res_fusion_mask(y4_handle h, int mask);
+
 /* Kernel launches of one y4_predict under the current fusion / tile settings (whole batch, no sub-batching):
  * `conv_family` = launches of the conv kernels other than the stem (what bench.py's roofline is quoted on),
  * `total` = all launches including stem, SPP, decode and NMS. */

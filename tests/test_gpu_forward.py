@@ -342,6 +342,57 @@ def test_stage_fusion_is_bit_identical(dtype, size, n):
     eng.close()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("size,n", [(96, 5), (160, 3), (416, 2), (608, 2)])
+def test_res_fusion_is_bit_identical(dtype, size, n):
+    """Residual blocks "1x1 -> 3x3 + Add" of the 64- and 128-channel stages (reference custom_layers.py:34-44: convs 11-12,
+    13-14 and 20-21 .. 34-35) as one spatially tiled kernel each (csrc/resblock.hip): the 1x1 conv runs in place on the
+    LDS-resident halo'd tile, the 3x3 reads its nine taps from it.  Same MFMAs on the same 16-bit inputs in the same K
+    order as the separate kernels -> every materialised tensor, the heads and the detections are bit-identical, including
+    partially filled edge tiles (sides 12, 20, 24, 40, 52, 76 are not multiples of the 16-pixel tile), the image border
+    (zero padding applies to the 1x1 conv's OUTPUT) and the existing chain fusions whose heads / tails the blocks take
+    over.  While a block runs fused its 1x1 conv is not materialised."""
+    import yolo4hip.ext as ext
+    cfg, plan, ws, imgs, eng = _setup(size, 3, n, dtype, seed=9)
+    heads = eng.forward_heads(imgs)
+    taps = (10, 12, 14, 16, 19, 21, 23, 29, 35, 36, 37)
+    ref = {i: eng.conv_output(i, n) for i in taps}
+    base = eng.predict(imgs, with_indices=True)
+
+    def check():
+        for a, b in zip(heads, eng.forward_heads(imgs)):
+            assert np.array_equal(a, b)
+        for i in taps:
+            assert np.array_equal(ref[i], eng.conv_output(i, n)), i
+        for a, b in zip(base, eng.predict(imgs, with_indices=True)):
+            assert np.array_equal(a, b)
+
+    assert eng.set_res_fusion(True) == 10 and eng.res_fusion_mask() == 3
+    check()
+    for idx in (11, 13, 20, 34):
+        with pytest.raises(ext.Y4Error):
+            eng.conv_output(idx, n)
+    eng.set_stem_fusion(True)
+    eng.set_chain_fusion(True)
+    eng.set_stage_fusion(True)
+    check()
+    if n > 1:
+        eng.set_subbatch(1, 16)
+        check()
+        eng.set_subbatch(0)
+    for mask in (1, 2):                      # one channel group fused, the other on its chains
+        eng.set_res_fusion_mask(mask)
+        assert eng.res_fusion_mask() == mask
+        check()
+    eng.set_res_fusion(True)
+    eng.autotune(n, reps=1)                  # keeps a group only where it measures faster; either way:
+    check()
+    eng.set_res_fusion(False)
+    assert eng.res_fusion_mask() == 0
+    check()
+    eng.close()
+
+
 def test_stem_fusion_rejected_where_unsupported():
     import yolo4hip.ext as ext
     cfg, plan, ws, imgs, eng = _setup(160, 3, 1, "f32")
@@ -351,6 +402,8 @@ def test_stem_fusion_rejected_where_unsupported():
         eng.set_chain_fusion(True)
     with pytest.raises(ext.Y4Error):
         eng.set_stage_fusion(True)
+    with pytest.raises(ext.Y4Error):
+        eng.set_res_fusion(True)
     eng.close()
 
 

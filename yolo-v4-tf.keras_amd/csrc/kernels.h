@@ -64,6 +64,14 @@ int pack_csp_stage(int dtype, const float* const* w, const float* const* scale, 
 int csp_stage_launch(int dtype, const void* in, int n, int side, int in_cstride, int in_coff, const void* blob, void* out,
                      int out_cstride, int out_coff, hipStream_t stream);
 
+// resblock.hip: "1x1 conv -> 3x3 conv + Add" residual blocks with 64 / 128 channels as one spatially tiled kernel
+bool resblock_supported(int dtype, int c);
+size_t resblock_blob_bytes(int c);
+int pack_resblock(int dtype, int c, const float* w1, const float* scale1, const float* shift1, const float* w3, const float* scale3,
+                  const float* shift3, void* blob, hipStream_t stream);
+int resblock_launch(int dtype, int c, const void* in, int n, int side, int in_cstride, int in_coff, const void* blob, void* out,
+                    int out_cstride, int out_coff, hipStream_t stream);
+
 // decode_nms.hip
 // Per-image candidate counters are spaced one per 256 bytes: packed into one cache line, the ~10^3 appends per
 // image of a whole batch serialise on a single L2 line (measured: decode 195 us -> see DESIGN.md).

@@ -67,6 +67,13 @@ struct Chain {
     int tile = 0;           // the head's tile when it runs chained (0 = heuristic); Op::tile stays the unfused choice
 };
 
+// A residual block "1x1 conv -> 3x3 conv + Add(block input)" executed as one spatially tiled kernel (resblock.hip)
+struct ResRun {
+    int head, tail;         // op indices of the 1x1 and the 3x3 conv
+    int c;                  // channels (64 | 128): the tuner decides per channel group
+    size_t blob_off = 0;    // fragment-ordered weights + affine in the wts workspace
+};
+
 }  // namespace y4
 
 using namespace y4;
@@ -111,6 +118,15 @@ struct y4_ctx {
     size_t stage_blob_off = 0;
     bool stage_on = false, stage_enabled = true;
     bool stage_active() const { return stage_first >= 0 && stage_on && stage_enabled; }
+    // residual blocks of the 128- and 64-channel stages as one kernel each; group 0 = C 128, group 1 = C 64
+    std::vector<ResRun> resruns;
+    bool res_on = false, res_enabled[2] = {true, true};
+    const ResRun* res_of(int oi, bool* is_head) const {
+        if (!res_on) return nullptr;
+        for (const ResRun& r : resruns)
+            if ((r.head == oi || r.tail == oi) && res_enabled[r.c == 128 ? 0 : 1]) { if (is_head) *is_head = r.head == oi; return &r; }
+        return nullptr;
+    }
     // images of the current call are uint8 frames at network size (y4_forward_u8 / y4_predict_u8): the stem divides by 255
     bool img_u8 = false;
 };
@@ -388,6 +404,28 @@ void find_stage(y4_ctx& c) {
     }
 }
 
+// residual_block (reference custom_layers.py:34-44) with filters1 == filters2 in {64, 128}: ops [1x1 C->C][3x3 C->C + Add(x)]
+void find_resruns(y4_ctx& c) {
+    if (c.cfg.dtype == Y4_F32) return;
+    const int nops = (int)c.ops.size();
+    for (int i = 0; i + 1 < nops; ++i) {
+        const Op &a = c.ops[i], &b = c.ops[i + 1];
+        if (a.kind != OP_CONV || b.kind != OP_CONV || a.conv2 >= 0 || b.conv2 >= 0 || a.has_res || !b.has_res) continue;
+        const Layer &la = c.layers[a.conv], &lb = c.layers[b.conv];
+        const int ch = la.d.cin;
+        if (!resblock_supported(c.cfg.dtype, ch)) continue;
+        if (!(la.d.ksize == 1 && la.d.cout == ch && la.d.act == Y4_ACT_MISH && la.d.has_bn && lb.d.ksize == 3 && lb.d.stride == 1 &&
+              lb.d.cin == ch && lb.d.cout == ch && lb.d.act == Y4_ACT_MISH && lb.d.has_bn))
+            continue;
+        if (!(same_view(b.in, a.out) && same_view(b.res, a.in)) || a.upsample || b.upsample || a.out_f32 || b.out_f32) continue;
+        bool leak = false;                         // the 1x1 conv's output must have no other reader
+        for (int k = 0; k < nops; ++k)
+            if (k != i + 1 && (c.ops[k].in.buf == a.out.buf || (c.ops[k].has_res && c.ops[k].res.buf == a.out.buf))) leak = true;
+        if (leak) continue;
+        c.resruns.push_back(ResRun{i, i + 1, ch});
+    }
+}
+
 void layout(y4_ctx& c) {
     // ---- activations
     size_t off = 0;
@@ -416,6 +454,7 @@ void layout(y4_ctx& c) {
         if (L.has_tail) { L.tail_off = off; off = align256(off + (size_t)L.d.cout * L.d.cin * c.es); }
     }
     if (c.stage_first >= 0) { c.stage_blob_off = off; off = align256(off + csp_stage_blob_bytes()); }
+    for (ResRun& r : c.resruns) { r.blob_off = off; off = align256(off + resblock_blob_bytes(r.c)); }
     c.wts_bytes = off;
 }
 
@@ -472,6 +511,22 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
                                 buf_ptr(h, o1.out, img0), o1.out.cstride, o1.out.coff, s);
     }
     if (h->fuse_stem && op.kind == OP_CONV && op.conv == 1) return Y4_OK;
+    if (allow_chain && op.kind == OP_CONV) {
+        bool is_head = false;
+        if (const ResRun* rr = h->res_of((int)(&op - h->ops.data()), &is_head)) {
+            if (!is_head) return Y4_OK;                          // the 3x3 conv ran inside its block's kernel
+            const Op& last = h->ops[rr->tail];
+            const int64_t per_img = (int64_t)op.in.side * op.in.side * op.in.cstride * h->es;
+            const int max_n = (int)(((1ll << 31) - 1) / per_img);
+            for (int i0 = 0; i0 < n; i0 += max_n) {
+                const int cnt = n - i0 < max_n ? n - i0 : max_n;
+                if (int r = resblock_launch(h->cfg.dtype, rr->c, buf_ptr(h, op.in, img0 + i0), cnt, op.in.side, op.in.cstride, op.in.coff,
+                                            h->wts + rr->blob_off, buf_ptr(h, last.out, img0 + i0), last.out.cstride, last.out.coff, s))
+                    return r;
+            }
+            return Y4_OK;
+        }
+    }
     if (allow_chain && h->stage_active() && op.kind == OP_CONV) {
         const int oi = (int)(&op - h->ops.data());
         if (oi > h->stage_first && oi <= h->stage_last) return Y4_OK;      // ran inside the stage kernel
@@ -492,7 +547,7 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
     const Chain* chain = nullptr;
     if (h->fuse_chains && allow_chain && op.kind == OP_CONV)
         for (const Chain& ch : h->chains) {
-            if (!ch.enabled) continue;
+            if (!ch.enabled || h->res_of(ch.head, nullptr)) continue;     // (a head inside a residual-block kernel: its tails run alone)
             if (&h->ops[ch.head] == &op) chain = &ch;
             else if (&h->ops[ch.tail[0]] == &op || (ch.tail[1] >= 0 && &h->ops[ch.tail[1]] == &op)) return Y4_OK;   // ran with its head
         }
@@ -636,6 +691,7 @@ int y4_create(const y4_config* cfg, y4_handle* out) {
     Builder(*c).build();
     find_chains(*c);
     find_stage(*c);
+    find_resruns(*c);
     layout(*c);
     *out = c;
     return Y4_OK;
@@ -725,6 +781,14 @@ int y4_pack_weights(y4_handle h, const float* blob, size_t n_floats, void* strea
         }
         if (int r = pack_csp_stage(h->cfg.dtype, w, sc, sh, h->wts + h->stage_blob_off, s)) return r;
     }
+    for (const ResRun& r : h->resruns) {
+        const Layer &L1 = h->layers[h->ops[r.head].conv], &L3 = h->layers[h->ops[r.tail].conv];
+        if (int rc = pack_resblock(h->cfg.dtype, r.c, blob + L1.d.weight_offset + 4 * (int64_t)L1.d.cout,
+                                   (const float*)(h->wts + L1.scale_off), (const float*)(h->wts + L1.shift_off),
+                                   blob + L3.d.weight_offset + 4 * (int64_t)L3.d.cout, (const float*)(h->wts + L3.scale_off),
+                                   (const float*)(h->wts + L3.shift_off), h->wts + r.blob_off, s))
+            return rc;
+    }
     h->weights_ready = true;
     return Y4_OK;
 }
@@ -787,6 +851,9 @@ int y4_get_conv_output(y4_handle h, int conv_idx, int n, float* out, size_t out_
             const int oi = (int)(&op - h->ops.data());
             Y4_REQUIRE(!(h->stage_active() && oi >= h->stage_first && oi < h->stage_last), Y4_ESTATE,
                        "conv %d is not materialised while the stage fusion is on", conv_idx);
+            bool is_head = false;
+            Y4_REQUIRE(!(h->res_of(oi, &is_head) && is_head), Y4_ESTATE,
+                       "conv %d is not materialised while the residual-block fusion is on", conv_idx);
         }
         const View& v = op.conv == conv_idx ? op.out : op.out2;
         const int64_t px = (int64_t)n * v.side * v.side;   // for an upsampling conv: the upsampled tensor
@@ -900,6 +967,7 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
     };
     auto images_of = [&](int oi) { return (h->sub_images > 0 && oi <= h->sub_last_op && n > h->sub_images) ? h->sub_images : n; };
     h->stage_enabled = false;          // passes 1 and 2 tune the stage's convs as separate kernels; pass 3 decides
+    h->res_enabled[0] = h->res_enabled[1] = false;      // likewise the residual-block kernels: pass 4
     // pass 1: every conv as its own kernel
     std::vector<float> best_ms(h->ops.size(), 0.f);
     for (int oi = 0; oi < (int)h->ops.size() && rc == Y4_OK; ++oi) {
@@ -990,6 +1058,37 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
         }
         h->stage_enabled = rc == Y4_OK && t_fused < t_sep;
     }
+    // pass 4: per channel group, the residual blocks as one kernel each against the same op range as tuned above
+    for (int grp = 0; grp < 2 && rc == Y4_OK && h->res_on; ++grp) {
+        int lo = -1, hi = -1;
+        for (const ResRun& r : h->resruns)
+            if ((r.c == 128 ? 0 : 1) == grp) { if (lo < 0) lo = r.head; hi = r.tail; }
+        if (lo < 0) continue;
+        // include the ops up to the end of the stage's residual chain consumers that existing chains may have fused with it
+        for (const Chain& ch : h->chains)
+            if (ch.head >= lo && ch.head <= hi) { if (ch.tail[0] > hi) hi = ch.tail[0]; if (ch.tail[1] > hi) hi = ch.tail[1]; }
+        const int ne = images_of(lo);
+        const int rounds = 4, per_round = reps > 3 ? reps : 3;
+        auto block = [&](bool fused) -> float {
+            h->res_enabled[grp] = fused;
+            if (hipEventRecord(e0, s) != hipSuccess) return -2.f;
+            for (int i = 0; i < per_round; ++i)
+                for (int oi = lo; oi <= hi; ++oi) run_op(h, h->ops[oi], nullptr, ne, s, 0, true);
+            float ms = 0.f;
+            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+                return -2.f;
+            return ms;
+        };
+        float t_fused = 0.f, t_sep = 0.f;
+        block(true); block(false);
+        for (int r = 0; r < rounds && rc == Y4_OK; ++r) {
+            const float a = block(true), b = block(false);
+            if (a == -2.f || b == -2.f) { rc = Y4_EHIP; break; }
+            t_fused += a; t_sep += b;
+        }
+        h->res_enabled[grp] = rc == Y4_OK && t_fused < t_sep;
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc != Y4_OK) set_error("y4_autotune: HIP event failure");
@@ -1065,6 +1164,32 @@ int y4_set_stage_fusion(y4_handle h, int on) {
     return h->stage_active() ? 1 : 0;
 }
 
+int y4_set_res_fusion(y4_handle h, int on) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(h->t_max_steps == 0, Y4_ESTATE, "y4_set_res_fusion: a timing session is open");
+    Y4_REQUIRE(!on || h->cfg.dtype != Y4_F32, Y4_EINVAL, "y4_set_res_fusion: 16-bit dtypes only");
+    h->res_on = on != 0;
+    h->res_enabled[0] = h->res_enabled[1] = true;
+    return on ? (int)h->resruns.size() : Y4_OK;
+}
+
+int y4_get_res_fusion(y4_handle h) {
+    if (int r = check_handle(h)) return r;
+    if (!h->res_on) return 0;
+    int mask = 0;
+    for (const ResRun& r : h->resruns) mask |= h->res_enabled[r.c == 128 ? 0 : 1] ? (r.c == 128 ? 1 : 2) : 0;
+    return mask;
+}
+
+int y4_set_res_fusion_mask(y4_handle h, int mask) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(h->cfg.dtype != Y4_F32 || mask == 0, Y4_EINVAL, "y4_set_res_fusion_mask: 16-bit dtypes only");
+    h->res_on = mask != 0;
+    h->res_enabled[0] = (mask & 1) != 0;
+    h->res_enabled[1] = (mask & 2) != 0;
+    return Y4_OK;
+}
+
 int y4_get_stage_fusion(y4_handle h) {
     if (int r = check_handle(h)) return r;
     return h->stage_active() ? 1 : 0;
@@ -1090,10 +1215,14 @@ static bool op_launches(y4_handle h, int oi) {
     const Op& op = h->ops[oi];
     if (op.kind != OP_CONV) return true;
     if (h->fuse_stem && op.conv == 1) return false;
+    {
+        bool is_head = false;
+        if (h->res_of(oi, &is_head)) return is_head;
+    }
     if (h->stage_active() && oi >= h->stage_first && oi <= h->stage_last) return oi == h->stage_first;
     if (h->fuse_chains)
         for (const Chain& ch : h->chains)
-            if (ch.enabled && (ch.tail[0] == oi || ch.tail[1] == oi)) return false;
+            if (ch.enabled && !h->res_of(ch.head, nullptr) && (ch.tail[0] == oi || ch.tail[1] == oi)) return false;
     return true;
 }
 

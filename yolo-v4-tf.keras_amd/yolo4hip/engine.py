@@ -435,6 +435,24 @@ class Engine:
             ext.check(r)
         return bool(r)
 
+    def set_res_fusion(self, on=True):
+        """Residual blocks of the 64- / 128-channel stages (1x1 -> 3x3 + Add) as one spatially tiled kernel each (16-bit
+        dtypes; bit-identical).  Returns the number of such blocks; `autotune` afterwards keeps them per channel group
+        only where they measure faster (`res_fusion_mask`: bit 0 = 128 channels, bit 1 = 64 channels)."""
+        r = self.lib.y4_set_res_fusion(self.handle, int(bool(on)))
+        if r < 0:
+            ext.check(r)
+        return r
+
+    def res_fusion_mask(self):
+        r = self.lib.y4_get_res_fusion(self.handle)
+        if r < 0:
+            ext.check(r)
+        return r
+
+    def set_res_fusion_mask(self, mask):
+        ext.check(self.lib.y4_set_res_fusion_mask(self.handle, int(mask)))
+
     def conv_launches_per_step(self):
         """Launches of the conv kernel family (everything but the stem) in one predict under the current settings."""
         convs, total = C.c_int32(), C.c_int32()

@@ -80,6 +80,9 @@ SYMBOLS = {
     "y4_set_chain_fusion": (_I, [_VP, _I]),
     "y4_set_stage_fusion": (_I, [_VP, _I]),
     "y4_get_stage_fusion": (_I, [_VP]),
+    "y4_set_res_fusion": (_I, [_VP, _I]),
+    "y4_get_res_fusion": (_I, [_VP]),
+    "y4_set_res_fusion_mask": (_I, [_VP, _I]),
     "y4_launch_counts": (_I, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "y4_timing_begin": (_I, [_VP, _I, _I]),
     "y4_timing_end": (_I, [_VP, _VP, _VP, _I, C.POINTER(_I), C.POINTER(_I), _VP]),
