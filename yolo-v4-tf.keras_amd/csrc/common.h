@@ -191,6 +191,13 @@ __device__ __forceinline__ void bn_act4(const f32x4_t& a, const float* sc, const
             const f32x2_t y = __builtin_elementwise_fma(-x, rr, x);
             out[r] = y.x; out[r + 1] = y.y;
         }
+    } else if constexpr (FAST) {
+        // LeakyReLU / linear on the 16-bit paths: the BN affine as packed FMAs (IEEE per element = fmaf), max(x, 0.1x) per element
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+            const f32x2_t x = __builtin_elementwise_fma(f32x2_t{a[r], a[r + 1]}, f32x2_t{sc[r], sc[r + 1]}, f32x2_t{sh[r], sh[r + 1]});
+            out[r] = apply_act_t<true, ACT>(x.x); out[r + 1] = apply_act_t<true, ACT>(x.y);
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[r] = apply_act_t<FAST, ACT>(fmaf(a[r], sc[r], sh[r]));

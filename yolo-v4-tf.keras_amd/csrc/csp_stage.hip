@@ -29,7 +29,7 @@
 #define CS_ABL 0
 #endif
 #ifndef CS_VMCNT
-#define CS_VMCNT 0
+#define CS_VMCNT 4                  // the 4 output stores of the previous tile (issued after its DMA, retired in order)
 #endif
 
 namespace y4 {
