@@ -8,8 +8,10 @@
 //      global memory into registers in the K layout of stem_common.h), BN + LeakyReLU applied, stored as 16-bit,
 //   3. the stride-2 3x3 conv runs out of LDS: 9 taps x (Wo/16) pixel fragments x 4 channel fragments of MFMAs,
 //   4. BN + LeakyReLU, 16-byte NHWC stores.
-// c0 never exists in HBM.  Each c0 row is computed by the two output rows that use it (1.5x stem recompute, a few
-// hundred cheap MFMAs).  LDS image of the c0 strip: [3 rows][2 column-parity planes][Wo+1 slots][64 B]; splitting
+// c0 never exists in HBM.  A workgroup is PERSISTENT over a band of consecutive output rows (9728 rows / 256 CUs = 38 at
+// 608x608 batch 32): the c1 weights are staged once, and the three c0 rows live in a 3-slot ring (c0 row y -> slot
+// (y + 1) mod 3), so going from output row ho to ho+1 keeps c0 row 2ho+1 and computes only the two new ones (the band's
+// first row and every image's first row compute all three): 1.03x stem work instead of the 1.5x of one workgroup per row.  LDS image of the c0 strip: [3 rows][2 column-parity planes][Wo+1 slots][64 B]; splitting
 // even and odd columns into planes turns the stride-2 tap walk into unit-stride slot reads (conflict-free with the
 // usual XOR swizzle), and slot 0 of the odd plane is the zero column left of the image.
 #include "conv_common.h"
@@ -46,9 +48,12 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
     const int MF = Wo >> 4;                                   // pixel fragments per output row
     char* const lds_w = smem;                                 // [9 taps][64 rows][64 B]
     char* const lds_s = smem + 9 * 64 * 64;                   // [3 rows][2 planes][PW slots][64 B]
-    const int n = blockIdx.x / Wo, ho = blockIdx.x - n * Wo;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane & 15, g = lane >> 4;
+    // this workgroup's band of output rows (row index = n * Wo + ho)
+    const int rows_total = p.N * Wo, per = (rows_total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int r_begin = blockIdx.x * per, r_end = min(r_begin + per, rows_total);
+    if (r_begin >= r_end) return;
 
     // ---- 1. c1 weights -> LDS.  LDS row (tap*64 + pr), pr = jn*16 + i, holds channel g'*16 + jn*4 + r'
     //         (i = g'*4 + r'), so that a lane's 16 accumulator values are 16 consecutive channels.
@@ -64,31 +69,52 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
         }
     }
 
-    // ---- 2. c0 rows 2ho-1, 2ho, 2ho+1 -> LDS (MFMA stem: stem_mfma_kernel's arithmetic, stem_common.h's K layout)
-    {
-        const u32x4 wf0 = p.stem_frag[lane], wf1 = p.stem_frag[64 + lane];
-        float sc[8], sh[8];
+    if (tid < 3 * 4) {                                        // the zero column left of the image, once for the three slots
+        const int row = ((tid >> 2) * 2 + 1) * PW;
+        *(u32x4*)(lds_s + row * 64 + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+    const u32x4 wf0 = p.stem_frag[lane], wf1 = p.stem_frag[64 + lane];
+    float sc0[8], sh0[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { sc[c] = p.s0_scale[g * 8 + c]; sh[c] = p.s0_shift[g * 8 + c]; }
+    for (int c = 0; c < 8; ++c) { sc0[c] = p.s0_scale[g * 8 + c]; sh0[c] = p.s0_shift[g * 8 + c]; }
+    const int wm = wave % SD_WM, wn = wave / SD_WM;
+    float sc1[8], sh1[8];
+#pragma unroll
+    for (int c = 0; c < 8; c += 4) {
+        const f32x4 s4 = *(const f32x4*)(p.s1_scale + g * 16 + wn * 8 + c);
+        const f32x4 h4 = *(const f32x4*)(p.s1_shift + g * 16 + wn * 8 + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc1[c + e] = s4[e]; sh1[c + e] = h4[e]; }
+    }
+
+    for (int orow_i = r_begin; orow_i < r_end; ++orow_i) {
+    const int n = orow_i / Wo, ho = orow_i - n * Wo;
+    // c0 rows 2ho-1+ry, ry = ry_first .. 2, are new; row 2ho-1 is the previous output row's 2(ho-1)+1, still in its slot
+    const int ry_first = (orow_i == r_begin || ho == 0) ? 0 : 1;
+    // ---- 2. c0 rows -> LDS ring (MFMA stem: stem_mfma_kernel's arithmetic, stem_common.h's K layout)
+    {
+        const float* sc = sc0; const float* sh = sh0;
         const int tiles_per_row = S >> 4;
-        const int ntiles = 3 * tiles_per_row;
+        const int ntiles = (3 - ry_first) * tiles_per_row;
         const IMG* const img_n = (const IMG*)p.img + (int64_t)n * S * S * 3;
         // this lane's share of a pixel's patch, relative to the tile's first pixel (stem_common.h): groups 0..2 read
         // floats 0..7 of row y+g-1's run, group 3 float 8 of the three runs
         const int lane_off = g < 3 ? ((g - 1) * S + q - 1) * 3 : (-S + q + 1) * 3 + 2;
         for (int t0 = wave; t0 < ntiles; t0 += SD_WAVES * SD_UNROLL) {
             float v[SD_UNROLL][8];
-            int xs[SD_UNROLL], rys[SD_UNROLL];          // rys: c0 row 0..2 | 4 if that row is outside the image
+            int xs[SD_UNROLL], rys[SD_UNROLL];          // rys: ring slot 0..2 of the c0 row | 4 if that row is outside the image
             int ys[SD_UNROLL], xts[SD_UNROLL];
             bool fast = true;                           // no tile of the batch is within 2 rows of the top / bottom border
 #pragma unroll
             for (int u = 0; u < SD_UNROLL; ++u) {
                 // wave-uniform (scalar registers).  Past the end: redo the last tile (same values to the same slots)
                 const int tile = min(t0 + u * SD_WAVES, ntiles - 1);
-                const int ry = (tile >= tiles_per_row) + (tile >= 2 * tiles_per_row);
-                const int xt = tile - ry * tiles_per_row, y = 2 * ho - 1 + ry;
+                const int rr = (tile >= tiles_per_row) + (tile >= 2 * tiles_per_row);
+                const int ry = ry_first + rr;
+                const int xt = tile - rr * tiles_per_row, y = 2 * ho - 1 + ry;
+                const int slot = (2 * ho + ry) % 3;              // ring slot of c0 row y = (y + 1) mod 3
                 xs[u] = xt * 16 + q; ys[u] = y; xts[u] = xt;
-                rys[u] = (unsigned)y < (unsigned)S ? ry : ry | 4;
+                rys[u] = (unsigned)y < (unsigned)S ? slot : slot | 4;
                 fast = fast && y >= 2 && y <= S - 3;      // rows y-1..y+1 inside, and the runs' overhang stays inside the image
             }
             // c0 value of (tile pixel, 8 channels) -> its slot of the strip.  column x: plane = x & 1; even plane slot
@@ -165,17 +191,12 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
                 }
             }
         }
-        if (tid < 3 * 4) {                                    // the zero column left of the image
-            const int row = ((tid >> 2) * 2 + 1) * PW;
-            *(u32x4*)(lds_s + row * 64 + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
-        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (orow_i == r_begin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the c1 weights (staged once)
     __syncthreads();
 
     // ---- 3. stride-2 3x3 conv out of LDS.  Wave (wm, wn): pixel fragments wm, wm+8, ... x channel fragments
     //         2wn, 2wn+1; taps outer so that a tap's weight fragments are read once per wave.
-    const int wm = wave % SD_WM, wn = wave / SD_WM;
     f32x4 acc[MFW][2];
 #pragma unroll
     for (int f = 0; f < MFW; ++f) acc[f][0] = acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -189,7 +210,7 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
             wf[j] = *(const u32x4*)(lds_w + row * 64 + ((g ^ sd_swz(row)) * 16));
         }
         // input column 2wo + kx - 1: kx = 0 -> odd plane slot wo, kx = 1 -> even plane slot wo, kx = 2 -> odd plane slot wo+1
-        const int row0 = (ky * 2 + (kx == 1 ? 0 : 1)) * PW + (kx == 2 ? 1 : 0) + q;
+        const int row0 = (((2 * ho + ky) % 3) * 2 + (kx == 1 ? 0 : 1)) * PW + (kx == 2 ? 1 : 0) + q;     // ring slot of c0 row 2ho-1+ky
 #pragma unroll
         for (int f = 0; f < MFW; ++f) {
             const int frag = wm + SD_WM * f;
@@ -203,14 +224,7 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
     }
 
     // ---- 4. BN + activation; the lane holds channels g*16 + wn*8 + (0..7) of its pixel -> one 16-byte store
-    float sc[8], sh[8];
-#pragma unroll
-    for (int c = 0; c < 8; c += 4) {
-        const f32x4 s4 = *(const f32x4*)(p.s1_scale + g * 16 + wn * 8 + c);
-        const f32x4 h4 = *(const f32x4*)(p.s1_shift + g * 16 + wn * 8 + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { sc[c + e] = s4[e]; sh[c + e] = h4[e]; }
-    }
+    const float* sc = sc1; const float* sh = sh1;
     T* const orow = (T*)p.out + ((int64_t)(n * Wo + ho) * Wo) * p.out_cstride + p.out_coff + g * 16 + wn * 8;
 #pragma unroll
     for (int f = 0; f < MFW; ++f) {
@@ -226,6 +240,8 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
             *(u32x4*)(orow + (int64_t)(frag * 16 + q) * p.out_cstride) = pk;
         }
     }
+    __syncthreads();                  // every wave has read the ring: the next row's stem may overwrite two of its slots
+    }                                 // output rows of the band
 }
 
 size_t stem_down_lds_bytes(int S) { return (size_t)9 * 64 * 64 + (size_t)3 * 2 * (S / 2 + 1) * 64; }
@@ -238,7 +254,17 @@ template <int DT, class IMG>
 static int stem_down_dispatch(const StemDownK& k, hipStream_t stream) {
     const int mfw = (k.S / 32 + SD_WM - 1) / SD_WM;         // ceil((Wo/16) / SD_WM)
     const size_t lds = stem_down_lds_bytes(k.S);
-    const int blocks = k.N * (k.S / 2);
+    // persistent: one workgroup per CU (LDS), each a contiguous band of the N * S/2 output rows
+    static int n_cus[64] = {0};
+    int dev = 0;
+    Y4_CHECK_HIP(hipGetDevice(&dev));
+    if (n_cus[dev & 63] == 0) {
+        int v = 0;
+        Y4_CHECK_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cus[dev & 63] = v > 0 ? v : 256;
+    }
+    const int rows = k.N * (k.S / 2);
+    const int blocks = rows < n_cus[dev & 63] ? rows : n_cus[dev & 63];
 #define Y4_SD_CASE(M)                                                                                        \
     case M: {                                                                                                \
         static PerDeviceOnce once;                                                                           \
