@@ -29,7 +29,10 @@
 #define CS_ABL 0
 #endif
 #ifndef CS_VMCNT
-#define CS_VMCNT 4                  // the 4 output stores of the previous tile (issued after its DMA, retired in order)
+// 0: the tile boundary drains everything.  4 would let the previous tile's 4 output stores stay in flight (measured: 583 ->
+// 578 us), but it relies on stores and LDS-DMA loads retiring in issue order RELATIVE TO EACH OTHER on one vmcnt counter,
+// which gfx9-family hardware does not promise (LLVM treats mixed pending loads / stores as out of order): not worth 1 %.
+#define CS_VMCNT 0
 #endif
 
 namespace y4 {
