@@ -425,6 +425,30 @@ def test_packed_weight_cache_roundtrip(tmp_path):
         e.close()
 
 
+def test_batch_beyond_the_2gib_descriptor_range_runs_in_chunks():
+    """the conv kernels address their input through a 2 GiB raw buffer descriptor.  An fp32 engine at 608x608 with
+    46 images has a 2.18 GB conv-0 output: such an op now runs as consecutive image chunks instead of failing with EINVAL on
+    the first forward.  Images are independent, so rows 0, 22 and 45 of the big batch must equal those images run alone."""
+    import torch
+    size, ncls, n = 608, 3, 46
+    cfg, plan, ws, imgs, eng = _setup(size, ncls, 3, "f32", seed=2)
+    one = [eng.predict(imgs[i:i + 1], with_indices=True) for i in range(3)]
+    eng.close()
+    from yolo4hip import weights as W
+    from yolo4hip.engine import Engine
+    big = Engine(ncls, cfg, max_batch=n, dtype="f32")
+    big.load_weight_blob(W.flatten(ws))
+    batch = torch.zeros((n, size, size, 3), dtype=torch.float32, device=big.device)
+    rows = (0, 22, 45)
+    for k, r in enumerate(rows):
+        batch[r] = torch.from_numpy(imgs[k]).to(big.device)
+    outs = [o.cpu().numpy() for o in big.predict_device(batch)]
+    for k, r in enumerate(rows):
+        for a, b in zip(outs, one[k]):
+            assert np.array_equal(a[r:r + 1], b), (r,)
+    big.close()
+
+
 def test_engine_fails_loudly():
     from yolo4hip import ext
     from yolo4hip.config import make_config
