@@ -107,6 +107,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
                               f"(or yolo-v4-tf.keras_amd/csrc/build.sh); there is no CPU fallback")
+        # torch first: PyTorch-ROCm bundles its own libamdhip64; if this library were loaded before it, the process would
+        # hold two HIP runtimes (the system one pulled in here, torch's later) and the one this library talks to then
+        # reports "no ROCm-capable device" while torch.cuda works -- seen when build() and smoke() share a process
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)          # AttributeError if the .so does not export it
