@@ -108,9 +108,8 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeK p) {
 // Variant for cells of at most 256 values (C <= 80): one wavefront per grid cell, the cell's 3*(5+C) logits are
 // read fully coalesced straight into registers (<= 4 per lane, one memory round trip), the three objectness
 // logits are broadcast by shuffles, and the 73 % of cells where no anchor can pass exit right there.
-// Cells per wave.  Measured on MI355X (608/80/batch 32): 1 cell 0.114 ms, 4 cells with all 16 loads issued up front 0.123 ms
-// -- the 73 % of waves that exit after the objectness screen are cheaper as short waves than as iterations of longer ones.
-constexpr int DC_CPW = 1;
+// (Round 2 also tried 4 cells per wave with all 16 full-cell loads issued up front: 0.123 ms against 0.114 for one cell per
+// wave; the objectness pre-screen of decode_cell_kernel below is what removed traffic instead.)
 
 struct DecodeCell { int n, s, rem; const float* src; };
 __device__ __forceinline__ DecodeCell decode_locate(const DecodeK& p, int64_t cellid) {
@@ -206,22 +205,43 @@ __device__ __forceinline__ void decode_one_cell(const DecodeK& p, const DecodeCe
     }
 }
 
+// A wave first SCREENS 16 consecutive cells: lane (c, a) = (lane >> 2, lane & 3 < 3) reads the one objectness logit of
+// (cell c, anchor a) -- 48 four-byte loads, three 64-byte sectors per cell instead of its 1 KB -- and the ballot of
+// sigmoid(obj) > threshold (the same float32 decision decode_one_cell makes) says which cells can have candidates at all
+// (27 % on the synthetic heads).  Only those are then read in full, one at a time.  HBM bytes per cell 1024 -> ~470.
+constexpr int DC_SCREEN = 16;
 __global__ __launch_bounds__(256) void decode_cell_kernel(const DecodeK p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t cell0 = ((int64_t)blockIdx.x * 4 + wave) * DC_CPW, ncell = (int64_t)p.N * p.cells_per_img;
+    const int64_t cell0 = ((int64_t)blockIdx.x * 4 + wave) * DC_SCREEN, ncell = (int64_t)p.N * p.cells_per_img;
     if (cell0 >= ncell) return;
-    const int nval = 3 * (5 + p.C);
-    DecodeCell cl[DC_CPW];
-    float v[DC_CPW][4];
-#pragma unroll
-    for (int c = 0; c < DC_CPW; ++c) {
-        cl[c] = decode_locate(p, cell0 + c < ncell ? cell0 + c : ncell - 1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[c][k] = (lane + 64 * k < nval) ? cl[c].src[lane + 64 * k] : 0.f;
+    const int nf = 5 + p.C, nval = 3 * nf;
+    const int c = lane >> 2, a = lane & 3;
+    bool pass = false;
+    if (a < 3 && cell0 + c < ncell) {
+        const DecodeCell cl = decode_locate(p, cell0 + c);
+        pass = sigmoid_f(cl.src[a * nf + 4]) > p.score_thr;
     }
+    unsigned long long m = __ballot(pass);
+    if (!m) return;
+    auto next_cell = [&](DecodeCell& cl, float (&v)[4]) {        // pops the lowest flagged cell and issues its loads
+        const int cc = (__ffsll((long long)m) - 1) >> 2;
+        m &= ~(0xFull << (4 * cc));
+        cl = decode_locate(p, cell0 + cc);
 #pragma unroll
-    for (int c = 0; c < DC_CPW; ++c)
-        if (cell0 + c < ncell) decode_one_cell(p, cl[c], v[c], lane);       // wave-uniform
+        for (int k = 0; k < 4; ++k) v[k] = (lane + 64 * k < nval) ? cl.src[lane + 64 * k] : 0.f;
+    };
+    DecodeCell cur, nxt;
+    float vc[4], vn[4];
+    next_cell(cur, vc);
+    while (true) {                                                // wave-uniform: the next flagged cell's loads fly under this one
+        const bool more = m != 0;
+        if (more) next_cell(nxt, vn);
+        decode_one_cell(p, cur, vc, lane);
+        if (!more) break;
+        cur = nxt;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vc[k] = vn[k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------- NMS
@@ -430,7 +450,7 @@ int decode_launch(const DecodeK& k, hipStream_t stream) {
     Y4_CHECK_HIP(hipMemsetAsync(k.counts, 0, sizeof(uint32_t) * k.N * COUNT_STRIDE, stream));
     if (3 * (5 + k.C) <= 256) {
         const int64_t cells = (int64_t)k.N * k.cells_per_img;
-        hipLaunchKernelGGL(decode_cell_kernel, dim3((int)((cells + 4 * DC_CPW - 1) / (4 * DC_CPW))), dim3(256), 0, stream, k);
+        hipLaunchKernelGGL(decode_cell_kernel, dim3((int)((cells + 4 * DC_SCREEN - 1) / (4 * DC_SCREEN))), dim3(256), 0, stream, k);
     } else {
         const int64_t boxes = (int64_t)k.N * k.nbox;
         hipLaunchKernelGGL(decode_kernel, dim3((int)((boxes + 255) / 256)), dim3(256), 0, stream, k);
