@@ -24,6 +24,24 @@
 
 namespace y4 {
 
+#ifdef Y4_TRACE
+// In-kernel phase trace (kernel experiments only; scripts/trace_read.py).  Build one translation
+// unit with -DY4_TRACE=1 -DY4_TRACE_BM=<BM> -DY4_TRACE_NST=<NST> (scripts/build_variant.sh): workgroup TR_WG of the plain
+// <BM> x 256 tile with <NST> stages records s_memtime (shader clock) per wave at fixed points of K-tiles TR_KT0 .. +3, and
+// s_memrealtime (100 MHz) once per K-tile, into y4_trace_buf[k-tile][wave][point]; y4_trace_read() copies it out.
+__device__ unsigned long long y4_trace_buf[4 * 8 * 8];
+#define TR_KT0 10
+#define TR_WG 8
+#define TR_POINT(P)                                                                                         \
+    do {                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (tr_on && kt >= TR_KT0 && kt < TR_KT0 + 4) asm volatile("s_memtime %0" : "=s"(tr_t[P]));         \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    } while (0)
+#else
+#define TR_POINT(P)
+#endif
+
 template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0, bool PAIR = false>
 __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel(const ConvK p) {
     constexpr int NT = 64 * WM * WN;
@@ -218,15 +236,32 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     for (int s = 0; s < SN - 1; ++s)
         if (s < nk) stage(s);
     int cur = 0, nxt = SN - 1;
+#ifdef Y4_TRACE
+    const bool tr_on = blockIdx.x == TR_WG && BM == Y4_TRACE_BM && BN == 256 && NST == Y4_TRACE_NST && CHAIN == 0 && !PAIR;
+    unsigned long long tr_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int kt = 0; kt < nk; ++kt) {
+        TR_POINT(0);                           // arrives at the K-tile barrier
+#ifdef Y4_TRACE
+        if (tr_on && kt >= TR_KT0 && kt < TR_KT0 + 4) asm volatile("s_memrealtime %0" : "=s"(tr_t[7]));
+#endif
         const int ahead = nk - 1 - kt;         // tiles issued after kt so far (capped at NST-2)
+#ifdef Y4_TRACE
+        if (SN == 2 || ahead == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TR_POINT(4);                       // this wave's own loads of tile kt have landed
+            asm volatile("s_barrier" ::: "memory");
+        } else
+#endif
         if (SN == 2 || ahead == 0) wait_vmcnt_then_barrier<0>();
         else if (a_skip) {                     // this wave issues one load fewer per stage (partial last A iteration)
             if (SN == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT - 1>();
             else wait_vmcnt_then_barrier<2 * (LPT - 1)>();
         } else if (SN == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT>();
         else wait_vmcnt_then_barrier<2 * LPT>();
+        TR_POINT(1);                           // past the barrier
         if (kt + SN - 1 < nk) stage(nxt);
+        TR_POINT(2);                           // next tile's loads issued (and the staging cursor advanced)
         const char* sx = lds_x + cur * STAGE;
         const char* sw = lds_w + cur * STAGE;
         cur = cur + 1 == SN ? 0 : cur + 1;
@@ -242,6 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 #pragma unroll
                 for (int j = 0; j < NREP; ++j) wf[kk][j] = *(const u32x4*)(sw + j * 16 * BKB + xo[kk]);
             }
+            TR_POINT(3);                       // fragment reads issued
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk)
@@ -250,6 +286,14 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 #pragma unroll
                     for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc[i][j], wf[kk][j], xf[kk][i]);
             __builtin_amdgcn_s_setprio(0);
+            TR_POINT(5);                       // last MFMA issued
+#ifdef Y4_TRACE
+            if (tr_on && kt >= TR_KT0 && kt < TR_KT0 + 4) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0)
+                    for (int q2 = 0; q2 < 8; ++q2) y4_trace_buf[((kt - TR_KT0) * 8 + wave) * 8 + q2] = tr_t[q2];
+            }
+#endif
         } else
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
