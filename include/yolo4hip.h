@@ -236,6 +236,10 @@ int y4_pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* o
  * optional UpSampling2D (custom_layers.py:147,159) + concat-slice store (custom_layers.py:68,...). */
 int y4_conv2d(const y4_conv_desc* d, void* stream);
 int y4_conv_tile_count(void);
+/* Tile configuration `tile` (1 .. y4_conv_tile_count()): cfg = {BM pixels, BN channels, waves over pixels, waves over
+ * channels, bytes of K per LDS row, schedule code (2..4 = ring stages, 12 = staggered 2-stage, 32 = 2-stage with the 32x32x16
+ * MFMA)}.  All tiles with the 16x16x32 MFMA give bit-identical results; the 32x32x16 tiles agree among themselves. */
+int y4_conv_tile_desc(int tile, int32_t cfg[6]);
 /* Stem conv (cin = 3, reference custom_layers.py:101): float32 images -> dtype.  `wk_dev` is an 8192-byte table
  * made by y4_pack_stem_weights from Darknet (cout,3,3,3) order: float32 [(ky*3+kx)*3+ci][cout] for the fp32
  * kernel, then (byte 4096 / 6144) the bf16 / fp16 MFMA weight fragments used by the 16-bit kernels. */

@@ -62,7 +62,7 @@ def run_conv_gpu(x, cw, k, stride, act, dtype, residual=None, upsample=False, ou
     sh = torch.zeros(cpad.value, dtype=torch.float32, device=dev); sh[:cout] = torch.from_numpy(shift).to(dev)
     d = ext.y4_conv_desc()
     d.dtype = did; d.n, d.h, d.w, d.cin = n, h, w, cin
-    d.cout, d.ksize, d.stride, d.act = cout, k, stride, {"mish": 2, "leaky": 1, None: 0}[act]
+    d.cout, d.ksize, d.stride, d.act = cout, k, stride, {"mish": 2, "leaky": 1, "linear": 0, None: 0}[act]
     d.upsample, d.out_f32 = int(upsample), int(out_f32)
     d.in_cstride, d.in_coff = in_cs, in_pad[0]
     d.out_cstride, d.out_coff = out_cs, out_pad[0]

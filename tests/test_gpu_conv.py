@@ -79,17 +79,66 @@ def test_all_tiles_agree(dtype):
     cw = make_conv_weights(rng, 128, 128, 3)
     cwq = ConvWeights(w=quantize(cw.w, dtype), bn=cw.bn)
     base, _ = run_conv_gpu(x, cwq, 3, 1, "mish", dtype)
-    ntiles = ext.load().y4_conv_tile_count()
-    ran = 0
+    import ctypes as C
+    lib = ext.load()
+    ntiles = lib.y4_conv_tile_count()
+    ran, base32, ran32 = 0, None, 0
+    atol, rtol = TOL[dtype]
     for tile in range(1, ntiles + 1):
+        cfg = (C.c_int32 * 6)()
+        ext.check(lib.y4_conv_tile_desc(tile, cfg))
         try:
             got, _ = run_conv_gpu(x, cwq, 3, 1, "mish", dtype, tile=tile)
         except ext.Y4Error as e:
-            assert e.code == -22      # tile does not fit this cin/cout: refused loudly, not computed wrongly
+            assert e.code == -22      # tile does not fit this cin/cout / dtype: refused loudly, not computed wrongly
+            continue
+        if cfg[5] == 32:              # 32x32x16 MFMA: another fp32 summation order; these agree among themselves
+            if base32 is None: base32 = got
+            assert np.array_equal(got, base32), f"32x32 tile {tile} differs from the first one: {np.abs(got - base32).max()}"
+            err = np.abs(got - base)
+            assert np.all(err <= 2 * atol + 2 * rtol * np.abs(base)), f"32x32 tile {tile}: {err.max():.3e} off the 16x16 tiles"
+            ran32 += 1
             continue
         ran += 1
         assert np.array_equal(got, base), f"tile {tile} differs: {np.abs(got - base).max()}"
-    assert ran >= 4
+    assert ran >= 4 and (dtype == "f32" or ran32 >= 2)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_mfma32_tiles_vs_oracle(dtype):
+    """The 32x32x16-MFMA tiles (schedule code 32) against the same float64 reference and tolerance as every other tile: a 3x3
+    conv with residual + Mish, a strided one and a 1x1 with a ragged pixel count and Cout = 255 (partial channel tile)."""
+    import ctypes as C
+    from yolo4hip import ext
+    from yolo4hip.weights import ConvWeights
+    lib = ext.load()
+    tiles32 = []
+    for tile in range(1, lib.y4_conv_tile_count() + 1):
+        cfg = (C.c_int32 * 6)()
+        ext.check(lib.y4_conv_tile_desc(tile, cfg))
+        if cfg[5] == 32: tiles32.append(tile)
+    assert len(tiles32) >= 3, tiles32
+    atol, rtol = TOL[dtype]
+    ran = 0
+    for (k, stride, cin, cout, side, act, use_res) in [(3, 1, 128, 256, 19, "mish", True), (3, 2, 64, 128, 26, "leaky", False),
+                                                       (1, 1, 512, 255, 13, "linear", False)]:
+        rng = np.random.default_rng(cin + cout)
+        x = quantize(rng.standard_normal((2, side, side, cin)).astype(np.float32), dtype)
+        cw = make_conv_weights(rng, cout, cin, k, act != "linear")
+        cwq = ConvWeights(w=quantize(cw.w, dtype), bn=cw.bn, bias=cw.bias)
+        so = side // stride
+        res = quantize(rng.standard_normal((2, so, so, cout)).astype(np.float32), dtype) if use_res else None
+        want = _ref(x, cwq, k, stride, act, res, False)
+        for tile in tiles32:
+            try:
+                got, _ = run_conv_gpu(x, cwq, k, stride, act, dtype, residual=res, tile=tile)
+            except ext.Y4Error as e:
+                assert e.code == -22
+                continue
+            err = np.abs(got - want)
+            assert np.all(err <= atol + rtol * np.abs(want)), f"tile {tile} {k}x{k} {cin}->{cout}: max err {err.max():.3e}"
+            ran += 1
+    assert ran >= 6
 
 
 def test_conv_rejects_bad_shapes():

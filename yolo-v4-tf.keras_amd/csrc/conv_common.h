@@ -7,6 +7,7 @@
 namespace y4 {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -78,6 +79,23 @@ template <> struct Mma<Y4_F16> {
     }
 };
 
+// 32x32x16 MFMA (16-bit dtypes): A = 32 weight rows x 16 k (lane: row lane&31, k 8*(lane>>5) ..+7), B = 32 pixels x 16 k,
+// D: lane (pixel lane&31, half lane>>5) holds rows 8*(i>>2) + 4*half + (i&3), i = 0..15
+template <int DT> struct Mma32;
+template <> struct Mma32<Y4_BF16> {
+    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma32<Y4_F16> {
+    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma32<Y4_F32> {     // (never instantiated for real: the fp32 path has no 32x32 tiles)
+    static __device__ __forceinline__ void run(f32x16&, const u32x4&, const u32x4&) {}
+};
+
 // buffer_load_dwordx4 ... lds: 16 bytes per lane from (descriptor base + voffset + soffset) to LDS at
 // (wave-uniform lds_dst + lane*16); lanes whose voffset is outside the descriptor's extent receive zeros.
 // Kept in a NON-template function: inside a template the target builtin is checked at instantiation time
@@ -105,15 +123,18 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_then_barrier() {
 //     bit-identical results.
 // The assignment is applied as a row permutation when the weight tile is staged (conv_igemm.hip, b_off).
 __device__ __forceinline__ int chunk_channel(int chw, int c, int fg) { return chw + (c * 4 + fg) * 8; }
+// The same with GW lane groups per wave: 4 for the 16x16 MFMA tiles (16 pixels per fragment, lane group = lane >> 4), 2 for
+// the 32x32x16 tiles (32 pixels per block, lane half = lane >> 5; a block's 16 accumulator values per lane are two chunks).
+template <int GW> __device__ __forceinline__ int chunk_channel_g(int chw, int c, int fg) { return chw + (c * GW + fg) * 8; }
 
 // ---- epilogue shared by the conv kernels: y = act(acc*scale + shift) (+ residual) -> NHWC slice store
 // (optionally 2x2 replicated, optionally split over two output views).  `mrow` is this lane's output pixel index
-// for fragment 0 (fragment i is 16 pixels further), pixels >= m_limit are not stored, `chw` is the first channel of
+// for fragment 0 (fragment i is 16 pixels further; 32 with GW = 2, see chunk_channel_g), pixels >= m_limit are not stored, `chw` is the first channel of
 // the wave's block.  FULL (block-uniform): no per-row / per-chunk predicates at all.
 // XL: the packed 16-bit tile is ALSO written to LDS at `xl` as Cout/64 consecutive [BM rows][128 B] panels (row =
 // pixel `xrow` + 16 i of the block, chunk index XOR-swizzled by the row like a staged activation tile), i.e. in the
 // layout the K loop reads its pixel operand from -- the input of a following 1x1 conv (LDS pair).
-template <int DT, int MREP, int NREP, int ACT, bool FULL, bool XL = false>
+template <int DT, int MREP, int NREP, int ACT, bool FULL, bool XL = false, int GW = 4>
 __device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[MREP][NREP], const float* sc,
                                                    const float* sh, int mrow, int m_limit, int chw, int fg,
                                                    char* xl = nullptr, int xrow = 0, int xpanel = 0) {
@@ -129,13 +150,13 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[
     bool second[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        ch[c] = chunk_channel(chw, c, fg);
+        ch[c] = chunk_channel_g<GW>(chw, c, fg);
         second[c] = p.split > 0 && ch[c] >= p.split;
         ooff[c] = second[c] ? p.out2_coff + ch[c] - p.split : p.out_coff + ch[c];
     }
 #pragma unroll
     for (int i = 0; i < MREP; ++i) {
-        const int m = mrow + i * 16;
+        const int m = mrow + i * (64 / GW);
         if (!FULL && m >= m_limit) continue;
         float v[NC * 8];
 #pragma unroll
@@ -183,6 +204,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[
             for (int k = 0; k < NC * 8; k += EPC) E::store_chunk(&packed[k / EPC], v + k);
             if constexpr (XL) {
                 static_assert(!XL || EPC == 8, "LDS pair: 16-bit dtypes");
+                static_assert(!XL || GW == 4, "LDS pair: 16x16 tiles");
                 const int row = xrow + i * 16;
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
@@ -201,14 +223,14 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[
     }
 }
 
-template <int DT, int MREP, int NREP, bool XL = false>
+template <int DT, int MREP, int NREP, bool XL = false, int GW = 4>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP][NREP], int mrow, int m_limit, int chw,
                                               int fg, bool full, char* xl = nullptr, int xrow = 0, int xpanel = 0) {
     constexpr int NC = NREP / 2;
     float sc[NC * 8], sh[NC * 8];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int ch = chunk_channel(chw, c, fg);
+        const int ch = chunk_channel_g<GW>(chw, c, fg);
 #pragma unroll
         for (int h = 0; h < 8; h += 4) {
             const f32x4 s4 = *(const f32x4*)(p.scale + ch + h);
@@ -219,14 +241,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP]
     }
     // the activation and the mask mode are compile-time inside; one uniform switch outside the pixel loop
     if (p.act == Y4_ACT_MISH) {
-        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, true, XL>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
-        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, false, XL>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
+        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, true, XL, GW>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
+        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, false, XL, GW>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
     } else if (p.act == Y4_ACT_LEAKY) {
-        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LEAKY, true, XL>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
-        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LEAKY, false, XL>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
+        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LEAKY, true, XL, GW>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
+        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LEAKY, false, XL, GW>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
     } else {
-        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, true, XL>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
-        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, false, XL>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
+        if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, true, XL, GW>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
+        else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, false, XL, GW>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
     }
 }
 

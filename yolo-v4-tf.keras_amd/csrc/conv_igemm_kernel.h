@@ -58,7 +58,9 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     constexpr int MREP = WPX / 16, NREP = WCH / 16;
     constexpr int CPL = 4 * NREP;           // consecutive channels a lane owns
     constexpr bool PHASED = (NST == 12);     // 2 LDS stages, two wave groups staggered by one of 4 phases per K-tile
-    constexpr int SN = PHASED ? 2 : NST;     // LDS stages
+    constexpr bool M32 = (NST == 32);        // 2 LDS stages, v_mfma_f32_32x32x16 (a different fp32 summation order: these
+                                             // tiles agree with each other bit for bit, not with the 16x16x32 ones)
+    constexpr int SN = (PHASED || M32) ? 2 : NST;     // LDS stages
     constexpr bool PREFRAG = true;           // all fragments of a K-tile are read before its first MFMA (measured: never slower)
     constexpr int STAGE = (BM + BN) * BKB;
     constexpr int KSTEPS = BKB / 64;        // MFMA k-steps (4 chunks each) per tile
@@ -68,6 +70,8 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     static_assert(SN >= 2 && SN <= 4 && (SN == 2 || !B_PART), "deep pipelines need uniform weight loads per wave");
     static_assert((SN - 2) * LPT <= 63, "vmcnt field");
     static_assert(!PHASED || (NT == 512 && KSTEPS == 2), "phased schedule: 8 waves, 128-byte K rows");
+    static_assert(!M32 || (DT != Y4_F32 && BKB == 128 && WPX % 32 == 0 && WCH % 32 == 0 && CHAIN == 0 && !PAIR && !B_PART),
+                  "32x32x16 tiles: 16-bit, 128-byte K rows, wave tile in 32x32 blocks, plain launches");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -96,6 +100,9 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     // tap that falls into the padding (or a row past M) gets an out-of-range voffset, which the hardware
     // bounds check turns into zeros -- no per-tile address arithmetic, no zero page.
     const int q = tid % CPR, r0 = tid / CPR;
+    // chunk swizzle of an LDS row: by the row's low bits (conv_common.h: swz); the 32x32x16 tiles also flip bit 0 with row
+    // bit 4 -- their fragment reads put rows r and r + 16 (not r and r + 8 with the next chunk) into one ds_read_b128 lane group
+    auto tswz = [](int row) { return M32 ? (swz<CPR>(row) ^ ((row >> 4) & 1)) : swz<CPR>(row); };
     int a_off[A_IT], a_hi[A_IT], a_wi[A_IT];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         const int n = (int)fastdiv((uint32_t)mm, p.div_howo), rem = mm - n * HoWo;
         const int ho = (int)fastdiv((uint32_t)rem, p.div_wo), wo = rem - ho * p.Wo;
         const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-        a_off[j] = (((n * p.H + hi0) * p.W + wi0) * p.in_cstride + p.in_coff + ((q ^ swz<CPR>(row)) * EPC)) * ES;
+        a_off[j] = (((n * p.H + hi0) * p.W + wi0) * p.in_cstride + p.in_coff + ((q ^ tswz(row)) * EPC)) * ES;
         a_hi[j] = m < p.M ? hi0 : -100000;     // rows past M never validate -> zeros
         a_wi[j] = wi0;
     }
@@ -116,9 +123,17 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         const int row = B_PART ? (r0 % BN) : (r0 + j * RPI);
         // LDS row (wave block, fragment jn, MFMA row i = g*4 + r)  <-  channel of the chunked layout (conv_common.h)
         const int wb = row / WCH, pr = row - wb * WCH;
-        const int jn = pr >> 4, i = pr & 15, g = i >> 2, r = i & 3;
-        const int ch = chunk_channel(n0 + wb * WCH, jn >> 1, g) + (jn & 1) * 4 + r;
-        b_off[j] = (ch * p.K + ((q ^ swz<CPR>(row)) * EPC)) * ES;
+        int ch;
+        if constexpr (M32) {
+            // MFMA row R = 8g + 4h + j of 32-row block jb is accumulator value 4g + j of lane half h: chunk 2 jb + (g >> 1)
+            // of that half (chunk_channel_g<2>), element 4 (g & 1) + j
+            const int jb = pr >> 5, R = pr & 31, g = R >> 3, hh = (R >> 2) & 1, jj = R & 3;
+            ch = chunk_channel_g<2>(n0 + wb * WCH, 2 * jb + (g >> 1), hh) + (g & 1) * 4 + jj;
+        } else {
+            const int jn = pr >> 4, i = pr & 15, g = i >> 2, r = i & 3;
+            ch = chunk_channel(n0 + wb * WCH, jn >> 1, g) + (jn & 1) * 4 + r;
+        }
+        b_off[j] = (ch * p.K + ((q ^ tswz(row)) * EPC)) * ES;
     }
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(p.wt, p.wt_bytes);
@@ -172,7 +187,77 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
-    if constexpr (PHASED) {
+    if constexpr (M32) {
+        // Same staging, same LDS image, same one-barrier 2-stage loop; the K-tile is 4 k-steps of 16 with 32x32 blocks:
+        // half the MFMA instructions for the same FLOPs and the same fragment bytes.
+        constexpr int MB = WPX / 32, NB = WCH / 32;
+        const int frow32 = lane & 31, fh = lane >> 5;
+        int xo32[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xo32[ks] = frow32 * 128 + (((2 * ks + fh) ^ tswz(frow32)) * 16);
+        f32x16 acc32[MB][NB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+        stage(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vmcnt_then_barrier<0>();
+            if (kt + 1 < nk) stage((kt + 1) & 1);
+            // (LDS byte addresses: the low 32 bits of a __shared__ pointer; the weight rows sit BM*BKB behind the pixel rows,
+            // which goes into the instruction offset together with the block index)
+            unsigned xa[4], wa[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                xa[ks] = (unsigned)(uintptr_t)(smem + (kt & 1) * STAGE + (wm * WPX) * BKB + xo32[ks]);
+                wa[ks] = (unsigned)(uintptr_t)(smem + (kt & 1) * STAGE + (wn * WCH) * BKB + xo32[ks]);
+            }
+            // The 20 fragment reads and their waits are written out (inline asm): left to the compiler, the first MFMA of
+            // the K-tile waits for lgkmcnt(0), i.e. for all 20 reads, instead of for its own k-step's five.
+            u32x4 xf[4][MB], wf[4][NB];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[ks][i]) : "v"(xa[ks]), "n"(i * 32 * 128));
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[ks][j]) : "v"(wa[ks]), "n"(BM * BKB + j * 32 * 128));
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                // k-step ks's MB + NB reads are complete once at most (3 - ks) * (MB + NB) are outstanding; the "+v" operands
+                // keep this k-step's MFMAs behind the wait
+                constexpr int R = MB + NB;                       // (the count field holds 15 at most: waiting for more is safe)
+                if (ks == 0) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xf[0][0]), "+v"(wf[0][0]) : "n"(3 * R > 15 ? 15 : 3 * R));
+                if (ks == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xf[1][0]), "+v"(wf[1][0]) : "n"(2 * R > 15 ? 15 : 2 * R));
+                if (ks == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xf[2][0]), "+v"(wf[2][0]) : "n"(R > 15 ? 15 : R));
+                if (ks == 3) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xf[3][0]), "+v"(wf[3][0]) : "n"(0));
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int i = 0; i < MB; ++i) Mma32<DT>::run(acc32[i][j], wf[ks][j], xf[ks][i]);
+                __builtin_amdgcn_sched_barrier(0);               // (MFMAs that do not read operand 0 would sink below the next wait)
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // the shared epilogue on a view of the blocks as f32x4 fragments: value 4f + r of block (i, j) = fragment 4j + f,
+        // i.e. chunk 2j + (f >> 1) of this lane half, element 4 (f & 1) + r
+        f32x4 accv[MB][NB * 4];
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    accv[i][j * 4 + f] = f32x4{acc32[i][j][4 * f], acc32[i][j][4 * f + 1], acc32[i][j][4 * f + 2], acc32[i][j][4 * f + 3]};
+        const bool full32 = (m0 + BM <= p.M) && (n0 + BN <= p.cout_store);
+        conv_epilogue<DT, MB, NB * 4, false, 2>(p, accv, m0 + wm * WPX + frow32, p.M, n0 + wn * WCH, fh, full32);
+        return;
+    } else if constexpr (PHASED) {
         // Staggered 4-phase schedule for one 8-wave workgroup per CU.  A K-tile is READ(k-step 0) | MMA | READ(k-step 1) |
         // MMA with a workgroup barrier after every phase; waves 4-7 run ONE phase behind waves 0-3 (they take one
         // extra barrier first, waves 0-3 one extra at the end), so while one group's 4 waves (one per SIMD) issue
@@ -387,7 +472,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 // ------------------------------------------------------------------------------------------- launch
 template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0, bool PAIR = false>
 static int launch_cfg(const ConvK& k, hipStream_t stream) {
-    constexpr int lds_main = (NST == 12 ? 2 : NST) * (BM + BN) * BKB + (CHAIN ? ChainShape<CHAIN ? CHAIN : 1>::LDS_BYTES : 0);
+    constexpr int lds_main = (NST == 12 || NST == 32 ? 2 : NST) * (BM + BN) * BKB + (CHAIN ? ChainShape<CHAIN ? CHAIN : 1>::LDS_BYTES : 0);
     constexpr int lds_pair = PAIR ? (BN / 64) * BM * 128 + 2 * BN * 128 : 0;     // tile panels + two weight stages of the tail
     constexpr int lds = lds_main > lds_pair ? lds_main : lds_pair;
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -411,6 +496,7 @@ static int launch_plain(int tile, const ConvK& k, hipStream_t s) {
 #define Y4_TILE_CASE(id, bm, bn, wm, wn, bkb, nst)                                            \
     case id:                                                                                  \
         if constexpr (DT == Y4_F32 && (id > F32_TILES)) break;                                \
+        else if constexpr (DT == Y4_F32 && nst == 32) break;                                  \
         else return launch_cfg<DT, bm, bn, wm, wn, bkb, nst>(k, s);
     switch (tile) { Y4_TILES(Y4_TILE_CASE) }
     set_error("conv2d: tile id %d is not available for this dtype", tile);

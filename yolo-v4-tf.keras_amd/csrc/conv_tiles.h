@@ -7,7 +7,8 @@ namespace y4 {
 struct TileCfg {
     int bm, bn, wm, wn, bkb, nst;
 };
-// id, BM (pixels), BN (channels), WM, WN (wave grid), BKB (bytes of K per LDS row), NST (ring stages).
+// id, BM (pixels), BN (channels), WM, WN (wave grid), BKB (bytes of K per LDS row), NST (ring stages; 12 = the staggered
+// 2-stage schedule, 32 = 2 stages with the 32x32x16 MFMA).
 // The table is also what tests and the autotuner sweep through y4_conv_desc.tile.
 #define Y4_TILES(X)            \
     X(1, 128, 128, 2, 2, 128, 2)  \
@@ -41,7 +42,12 @@ struct TileCfg {
     X(29, 112, 128, 1, 4, 128, 2) \
     X(30, 192, 256, 2, 4, 128, 12) \
     X(31, 256, 256, 2, 4, 128, 12) \
-    X(32, 224, 256, 2, 4, 128, 12)
+    X(32, 224, 256, 2, 4, 128, 12) \
+    X(33, 192, 256, 2, 4, 128, 32) \
+    X(34, 256, 256, 2, 4, 128, 32) \
+    X(35, 128, 256, 2, 4, 128, 32) \
+    X(36, 128, 128, 2, 2, 128, 32) \
+    X(37, 256, 128, 4, 2, 128, 32)
 
 #define Y4_TILE_ROW(id, bm, bn, wm, wn, bkb, nst) {bm, bn, wm, wn, bkb, nst},
 static const TileCfg kTiles[] = {Y4_TILES(Y4_TILE_ROW)};

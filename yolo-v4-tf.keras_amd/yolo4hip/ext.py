@@ -90,6 +90,7 @@ SYMBOLS = {
     "y4_pack_conv_weights": (_I, [_I, _I, _I, _I, _VP, _VP, _VP]),
     "y4_conv2d": (_I, [C.POINTER(y4_conv_desc), _VP]),
     "y4_conv_tile_count": (_I, []),
+    "y4_conv_tile_desc": (_I, [_I, C.POINTER(C.c_int32)]),
     "y4_pack_stem_weights": (_I, [_VP, _VP, _I, _VP]),
     "y4_stem_conv": (_I, [_I, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _I, _VP]),
     "y4_preprocess_u8": (_I, [_VP, _I, _I, _VP, _I, _I, _VP]),
