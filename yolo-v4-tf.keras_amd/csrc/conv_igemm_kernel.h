@@ -513,7 +513,7 @@ static int launch_fused(int tile, const ConvK& k, hipStream_t s) {
                 Y4_PAIR_CASE(1, 128, 128, 2, 2) Y4_PAIR_CASE(8, 64, 128, 1, 4) Y4_PAIR_CASE(20, 96, 128, 2, 2)
                 Y4_PAIR_CASE(24, 160, 128, 2, 2) Y4_PAIR_CASE(25, 192, 128, 2, 2) Y4_PAIR_CASE(29, 112, 128, 1, 4)
                 Y4_PAIR_CASE(13, 128, 256, 2, 4) Y4_PAIR_CASE(19, 192, 256, 2, 4) Y4_PAIR_CASE(21, 96, 256, 2, 4)
-                Y4_PAIR_CASE(22, 160, 256, 2, 4)
+                Y4_PAIR_CASE(22, 160, 256, 2, 4) Y4_PAIR_CASE(38, 384, 128, 4, 2)
             }
 #undef Y4_PAIR_CASE
         }

@@ -47,7 +47,8 @@ struct TileCfg {
     X(34, 256, 256, 2, 4, 128, 32) \
     X(35, 128, 256, 2, 4, 128, 32) \
     X(36, 128, 128, 2, 2, 128, 32) \
-    X(37, 256, 128, 4, 2, 128, 32)
+    X(37, 256, 128, 4, 2, 128, 32) \
+    X(38, 384, 128, 4, 2, 128, 2)
 
 #define Y4_TILE_ROW(id, bm, bn, wm, wn, bkb, nst) {bm, bn, wm, wn, bkb, nst},
 static const TileCfg kTiles[] = {Y4_TILES(Y4_TILE_ROW)};
@@ -60,7 +61,7 @@ inline bool chain_tile(int tile) { return tile == 3 || tile == 4 || tile == 15; 
 
 // LDS-pair heads: 128-byte K rows, 2 stages, one channel tile over all of Cout (128 or 256), tile + tail stages in LDS
 inline bool pair_tile(int tile) {
-    switch (tile) { case 1: case 8: case 20: case 24: case 25: case 29: case 13: case 19: case 21: case 22: return true; }
+    switch (tile) { case 1: case 8: case 20: case 24: case 25: case 29: case 13: case 19: case 21: case 22: case 38: return true; }
     return false;
 }
 
