@@ -73,6 +73,8 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
         const int row = ((tid >> 2) * 2 + 1) * PW;
         *(u32x4*)(lds_s + row * 64 + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
     }
+    const int64_t img_bytes = (int64_t)p.N * S * S * 3 * (int64_t)sizeof(IMG);
+    const __amdgpu_buffer_rsrc_t rs_img = make_rsrc(p.img, img_bytes < 0xffffffffll ? (unsigned)img_bytes : 0xffffffffu);
     const u32x4 wf0 = p.stem_frag[lane], wf1 = p.stem_frag[64 + lane];
     float sc0[8], sh0[8];
 #pragma unroll
@@ -195,6 +197,16 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
     if (orow_i == r_begin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the c1 weights (staged once)
     __syncthreads();
 
+    // ---- L2 prefetch of the image rows the NEXT output row's stem will read for the first time (two rows, contiguous
+    //      in memory; three at an image's first row): one LDS-DMA load per wave into a scratch KB -- no registers, nobody
+    //      reads the data; the stem's patch loads, whose round trip is not overlapped with anything, then hit L2.
+    if (orow_i + 1 < r_end) {
+        const int n2 = (orow_i + 1) / Wo, ho2 = orow_i + 1 - n2 * Wo;
+        const int64_t byte0 = (((int64_t)n2 * S + (ho2 == 0 ? 0 : 2 * ho2 + 1)) * S * 3) * (int64_t)sizeof(IMG);
+        if (byte0 + SD_WAVES * 1024 < (int64_t)0x7fffffff)
+            buffer_load16_lds(rs_img, lds_s + 3 * 2 * PW * 64, (int)byte0 + wave * 1024 + lane * 16, 0);
+    }
+
     // ---- 3. stride-2 3x3 conv out of LDS.  Wave (wm, wn): pixel fragments wm, wm+8, ... x channel fragments
     //         2wn, 2wn+1; taps outer so that a tap's weight fragments are read once per wave.
     f32x4 acc[MFW][2];
@@ -244,7 +256,8 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
     }                                 // output rows of the band
 }
 
-size_t stem_down_lds_bytes(int S) { return (size_t)9 * 64 * 64 + (size_t)3 * 2 * (S / 2 + 1) * 64; }
+// c1 weights + c0 ring + the prefetch's scratch KB
+size_t stem_down_lds_bytes(int S) { return (size_t)9 * 64 * 64 + (size_t)3 * 2 * (S / 2 + 1) * 64 + 1024; }
 
 bool stem_down_supported(int dtype, int S) {
     return dtype != Y4_F32 && S % 32 == 0 && stem_down_lds_bytes(S) <= 160 * 1024 && (S / 32 + SD_WM - 1) / SD_WM <= 3;
