@@ -123,7 +123,25 @@ __device__ __forceinline__ DecodeCell decode_locate(const DecodeK& p, int64_t ce
     return c;
 }
 
-__device__ __forceinline__ void decode_one_cell(const DecodeK& p, const DecodeCell& cl, const float (&v)[4], int lane) {
+// A wave's candidates are staged in its own LDS slice and go out with ONE returning atomic per flush (image change, slice
+// nearly full, end of the wave's cells) instead of one per cell: the atomic's round trip -- the wave can do nothing until it
+// knows where to write -- was paid 4-5 times per wave, and an image's counter took four times the same-address atomics.
+// The order of an image's candidate list is irrelevant (NMS sorts it; keys are unique).
+constexpr int DC_STAGE = 512;               // keys per wave slice; a cell yields at most 3 * C <= 240
+struct DecodeStage { unsigned long long* slice; uint32_t fill; int img; };
+__device__ __forceinline__ void decode_flush(const DecodeK& p, DecodeStage& st, int lane) {
+    if (st.fill) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(p.counts + (size_t)st.img * COUNT_STRIDE, st.fill);
+        base = __shfl(base, 0);
+        unsigned long long* keys = p.keys + (int64_t)st.img * p.cap;
+        for (uint32_t i = lane; i < st.fill; i += 64)
+            if (base + i < p.cap) keys[base + i] = st.slice[i];
+        st.fill = 0;
+    }
+}
+
+__device__ __forceinline__ void decode_one_cell(const DecodeK& p, const DecodeCell& cl, const float (&v)[4], int lane, DecodeStage& st) {
     const int n = cl.n, s = cl.s, rem = cl.rem;
     const int g = p.g[s];
     const int nf = 5 + p.C, nval = 3 * nf;
@@ -141,7 +159,7 @@ __device__ __forceinline__ void decode_one_cell(const DecodeK& p, const DecodeCe
     }
     if (!any) return;                       // wave-uniform
     const int box0 = p.box_off[s] + rem * 3;
-    unsigned long long* keys = p.keys + (int64_t)n * p.cap;
+    if (n != st.img || st.fill + 3 * p.C > DC_STAGE) { decode_flush(p, st, lane); st.img = n; }     // wave-uniform
     const float cut = 0.998f * p.score_thr;
     unsigned long long key[4];
     unsigned long long mask[4];
@@ -170,18 +188,15 @@ __device__ __forceinline__ void decode_one_cell(const DecodeK& p, const DecodeCe
         mask[k] = __ballot(hit);
         total += (uint32_t)__popcll(mask[k]);
     }
-    if (total) {                              // ONE atomic per cell
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(p.counts + (size_t)n * COUNT_STRIDE, total);
-        base = __shfl(base, 0);
+    if (total) {                              // into the wave's slice; no atomic here
+        uint32_t base = st.fill;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if ((mask[k] >> lane) & 1ull) {
-                const uint32_t pos = base + (uint32_t)__popcll(mask[k] & ((1ull << lane) - 1ull));
-                if (pos < p.cap) keys[pos] = key[k];
-            }
+            if ((mask[k] >> lane) & 1ull)
+                st.slice[base + (uint32_t)__popcll(mask[k] & ((1ull << lane) - 1ull))] = key[k];
             base += (uint32_t)__popcll(mask[k]);
         }
+        st.fill = base;
     }
     // box coordinates of the anchors that can have candidates (custom_layers.py:251-256)
     float t[4];
@@ -230,18 +245,21 @@ __global__ __launch_bounds__(256) void decode_cell_kernel(const DecodeK p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = (lane + 64 * k < nval) ? cl.src[lane + 64 * k] : 0.f;
     };
+    __shared__ unsigned long long stage[4][DC_STAGE];
+    DecodeStage st{stage[wave], 0u, -1};
     DecodeCell cur, nxt;
     float vc[4], vn[4];
     next_cell(cur, vc);
     while (true) {                                                // wave-uniform: the next flagged cell's loads fly under this one
         const bool more = m != 0;
         if (more) next_cell(nxt, vn);
-        decode_one_cell(p, cur, vc, lane);
+        decode_one_cell(p, cur, vc, lane, st);
         if (!more) break;
         cur = nxt;
 #pragma unroll
         for (int k = 0; k < 4; ++k) vc[k] = vn[k];
     }
+    decode_flush(p, st, lane);
 }
 
 // ------------------------------------------------------------------------------------------- NMS
