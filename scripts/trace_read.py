@@ -12,6 +12,8 @@ offsets of the trace points and the time spent between them.
   dma      next tile's LDS-DMA instructions issued, staging cursor advanced
   reads    the K-tile's fragment reads (ds_read_b128) issued
   mma      the K-tile's last MFMA issued
+and the workgroup's life outside the K loop: kernel entry, staging set-up done, first K-tile's barrier passed, K loop done,
+epilogue done (stores issued), with the wall time from s_memrealtime.
 The traced K-tiles are ~10 % longer than untraced ones (8 timestamp stores per wave at the end of each)."""
 import ctypes as C
 import json
@@ -63,9 +65,21 @@ for kt in range(4):
         r = a[kt, w] - t0
         print("  wave %d: " % w + "  ".join("%s %6d" % (names[i], r[i]) for i in range(6)) +
               "   | dt: " + " ".join("%5d" % (r[i + 1] - r[i]) for i in range(5)))
+life = (C.c_ulonglong * 64)()
+lib.y4_trace_read_life.restype = C.c_int
+assert lib.y4_trace_read_life(life) == 0
+L = np.array(life[:], dtype=np.int64).reshape(8, 8)
+l0 = L[:, 0].min()
+lnames = ["entry", "set-up done", "first tile in", "K loop done", "epilogue done"]
+print("workgroup life outside the K loop (shader cycles from the first wave's entry):")
+for w in range(8):
+    r = L[w, :5] - l0
+    print("  wave %d: " % w + "  ".join("%s %6d" % (lnames[i], r[i]) for i in range(5)) +
+          "   | dt: " + " ".join("%6d" % (r[i + 1] - r[i]) for i in range(4)) + "   (%.2f us wall)" % ((L[w, 6] - L[w, 5]) / 100.0))
 if out_json:
     json.dump({"conv": only, "tile": tile, "workgroup": 8, "k_tiles": [10, 11, 12, 13], "points": names,
                "shader_clock_ghz": round(float(clock), 3), "cycles_per_traced_k_tile": round(float(dc) / 3, 1),
-               "cycles": (a - t0).tolist(),
+               "cycles": (a - t0).tolist(), "life_points": lnames, "life_cycles": (L[:, :5] - l0).tolist(),
+               "life_wall_us": ((L[:, 6] - L[:, 5]) / 100.0).tolist(),
                "note": "cycles[k_tile][wave][point], shader-clock cycles from the first arrival; traced K-tiles carry ~10 % "
                        "extra (timestamp stores)"}, open(out_json, "w"), indent=1)

@@ -11,4 +11,7 @@ int conv_launch_bf16(int tile, const ConvK& k, hipStream_t s) { return launch_pl
 extern "C" int y4_trace_read(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(y4::y4_trace_buf), sizeof(unsigned long long) * 4 * 8 * 8);
 }
+extern "C" int y4_trace_read_life(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(y4::y4_trace_life), sizeof(unsigned long long) * 8 * 8);
+}
 #endif

@@ -30,6 +30,15 @@ namespace y4 {
 // <BM> x 256 tile with <NST> stages records s_memtime (shader clock) per wave at fixed points of K-tiles TR_KT0 .. +3, and
 // s_memrealtime (100 MHz) once per K-tile, into y4_trace_buf[k-tile][wave][point]; y4_trace_read() copies it out.
 __device__ unsigned long long y4_trace_buf[4 * 8 * 8];
+// ... and the workgroup's life outside the K loop: [wave][0 entry, 1 staging set-up done, 2 first K-tile's barrier passed,
+// 3 K loop done, 4 epilogue done (stores issued), 5 s_memrealtime at entry, 6 s_memrealtime at the end]
+__device__ unsigned long long y4_trace_life[8 * 8];
+#define TR_LIFE(P, INSN)                                                                                    \
+    do {                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (tr_life_on) asm volatile(INSN " %0" : "=s"(tr_life[P]));                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    } while (0)
 #define TR_KT0 10
 #define TR_WG 8
 #define TR_POINT(P)                                                                                         \
@@ -40,6 +49,7 @@ __device__ unsigned long long y4_trace_buf[4 * 8 * 8];
     } while (0)
 #else
 #define TR_POINT(P)
+#define TR_LIFE(P, INSN)
 #endif
 
 template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0, bool PAIR = false>
@@ -88,6 +98,12 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
+#ifdef Y4_TRACE
+    const bool tr_life_on = blockIdx.x == TR_WG && BM == Y4_TRACE_BM && BN == 256 && NST == Y4_TRACE_NST && CHAIN == 0 && !PAIR;
+    unsigned long long tr_life[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    TR_LIFE(0, "s_memtime");
+    TR_LIFE(5, "s_memrealtime");
     ChainPrefetch<CHAIN != 0 ? MREP : 1> chain_pf;
     if constexpr (CHAIN != 0) {
         chain_stage_weights<CHAIN, WM * WN>(p, smem + SN * STAGE, __builtin_amdgcn_readfirstlane(wave), lane);
@@ -187,6 +203,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
+    TR_LIFE(1, "s_memtime");
     if constexpr (M32) {
         // Same staging, same LDS image, same one-barrier 2-stage loop; the K-tile is 4 k-steps of 16 with 32x32 blocks:
         // half the MFMA instructions for the same FLOPs and the same fragment bytes.
@@ -345,6 +362,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         } else if (SN == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT>();
         else wait_vmcnt_then_barrier<2 * LPT>();
         TR_POINT(1);                           // past the barrier
+        if (kt == 0) TR_LIFE(2, "s_memtime");
         if (kt + SN - 1 < nk) stage(nxt);
         TR_POINT(2);                           // next tile's loads issued (and the staging cursor advanced)
         const char* sx = lds_x + cur * STAGE;
@@ -464,8 +482,18 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         conv_epilogue<DT, MREP, NREP>(p2, acc2, mrow, p.M, chw, fg, (m0 + BM <= p.M) && BN <= p2.cout_store);
         if (p.store_x) pair_store_tile<DT, MREP, NREP>(p, xl, xrow, XPANEL, mrow, p.M, chw, fg);
     } else {
+        TR_LIFE(3, "s_memtime");
         const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.cout_store);
         conv_epilogue<DT, MREP, NREP>(p, acc, m0 + wm * WPX + frow, p.M, n0 + wn * WCH, fg, full);
+        TR_LIFE(4, "s_memtime");
+        TR_LIFE(6, "s_memrealtime");
+#ifdef Y4_TRACE
+        if (tr_life_on) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0)
+                for (int q2 = 0; q2 < 8; ++q2) y4_trace_life[wave * 8 + q2] = tr_life[q2];
+        }
+#endif
     }
 }
 
