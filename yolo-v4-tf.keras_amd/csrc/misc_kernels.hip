@@ -263,10 +263,44 @@ __global__ __launch_bounds__(256) void spp_kernel(typename Elem<DT>::type* __res
 // writes the three concat slices: 40 LDS reads per output chunk instead of 169 global loads.
 // CPG = 16-byte channel chunks per workgroup: 2 (46 KB of LDS at 19x19 -> three workgroups per CU overlap their load / pool /
 // store phases: 0.059 -> 0.045 ms; 1 chunk: 0.054) instead of 4 (92 KB, one workgroup per CU).
+// Packed max in the storage type: the pooling compares 16-byte chunks without unpacking them to float.  fp16: v_pk_max_f16.
+// bf16 has no packed max: a chunk is kept in "sortable" form (x ^ 0x7fff when the sign bit is set -- an involution that keeps
+// the sign bit, after which signed 16-bit order is float order) from the staging load to the final store, and the max is
+// v_pk_max_i16.  fp32: fmaxf.  max is exact in every form (signed zeros may come out as +0 where fmaxf kept -0).
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+template <int DT> struct PMax;
+template <> struct PMax<Y4_BF16> {
+    static __device__ __forceinline__ u32x4 enc(const u32x4& r) { return r ^ (((r >> 15) & 0x00010001u) * 0x7fffu); }
+    static __device__ __forceinline__ u32x4 dec(const u32x4& r) { return enc(r); }
+    static __device__ __forceinline__ u32x4 mx(const u32x4& a, const u32x4& b) {
+        return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(i16x8, a), __builtin_bit_cast(i16x8, b)));
+    }
+    static __device__ __forceinline__ u32x4 lowest() { return enc(u32x4{0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u}); }
+};
+template <> struct PMax<Y4_F16> {
+    static __device__ __forceinline__ u32x4 enc(const u32x4& r) { return r; }
+    static __device__ __forceinline__ u32x4 dec(const u32x4& r) { return r; }
+    static __device__ __forceinline__ u32x4 mx(const u32x4& a, const u32x4& b) {
+        return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b)));
+    }
+    static __device__ __forceinline__ u32x4 lowest() { return u32x4{0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u}; }
+};
+template <> struct PMax<Y4_F32> {
+    static __device__ __forceinline__ u32x4 enc(const u32x4& r) { return r; }
+    static __device__ __forceinline__ u32x4 dec(const u32x4& r) { return r; }
+    static __device__ __forceinline__ u32x4 mx(const u32x4& a, const u32x4& b) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(f4, a), __builtin_bit_cast(f4, b)));
+    }
+    static __device__ __forceinline__ u32x4 lowest() { return u32x4{0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u}; }
+};
+
 template <int DT, int CPG>
 __global__ __launch_bounds__(256) void spp_lds_kernel(typename Elem<DT>::type* __restrict__ buf, int N, int S, int C) {
     using E = Elem<DT>;
     using T = typename E::type;
+    using M = PMax<DT>;
     constexpr int EPC = E::EPC;
     extern __shared__ __attribute__((aligned(16))) char ssm[];
     const int P = S * S;
@@ -281,61 +315,46 @@ __global__ __launch_bounds__(256) void spp_lds_kernel(typename Elem<DT>::type* _
     const int ch0 = g * CPG * EPC;
     for (int t = threadIdx.x; t < P * CPG; t += 256) {
         const int px = t / CPG, q = t - px * CPG;
-        X[t] = *(const u32x4*)(img + (int64_t)px * cs + 3 * C + ch0 + q * EPC);
+        X[t] = M::enc(*(const u32x4*)(img + (int64_t)px * cs + 3 * C + ch0 + q * EPC));
     }
     __syncthreads();
-    auto upd = [](float* m, const u32x4& raw) {
-        float v[EPC];
-        E::load_chunk(&raw, v);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) m[e] = fmaxf(m[e], v[e]);
-    };
-    auto pack = [](const float* m) {
-        u32x4 o;
-        E::store_chunk(&o, m);
-        return o;
-    };
     for (int t = threadIdx.x; t < P * CPG; t += 256) {
         const int px = t / CPG, q = t - px * CPG;
         const int y = px / S, x = px - y * S;
-        float m[EPC];
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) m[e] = -INFINITY;
+        u32x4 m = M::lowest();
         const u32x4* row = X + (y * S) * CPG + q;
         for (int dx = -2; dx <= 2; ++dx)
-            if ((unsigned)(x + dx) < (unsigned)S) upd(m, row[(x + dx) * CPG]);
-        H2[t] = pack(m);
+            if ((unsigned)(x + dx) < (unsigned)S) m = M::mx(m, row[(x + dx) * CPG]);
+        H2[t] = m;
         for (int k = 3; k <= 4; ++k) {
-            if (x - k >= 0) upd(m, row[(x - k) * CPG]);
-            if (x + k < S) upd(m, row[(x + k) * CPG]);
+            if (x - k >= 0) m = M::mx(m, row[(x - k) * CPG]);
+            if (x + k < S) m = M::mx(m, row[(x + k) * CPG]);
         }
-        H4[t] = pack(m);
+        H4[t] = m;
         for (int k = 5; k <= 6; ++k) {
-            if (x - k >= 0) upd(m, row[(x - k) * CPG]);
-            if (x + k < S) upd(m, row[(x + k) * CPG]);
+            if (x - k >= 0) m = M::mx(m, row[(x - k) * CPG]);
+            if (x + k < S) m = M::mx(m, row[(x + k) * CPG]);
         }
-        H6[t] = pack(m);
+        H6[t] = m;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < P * CPG; t += 256) {
         const int px = t / CPG, q = t - px * CPG;
         const int y = px / S, x = px - y * S;
-        float m5[EPC], m9[EPC], m13[EPC];
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) m5[e] = m9[e] = m13[e] = -INFINITY;
+        u32x4 m5 = M::lowest(), m9 = m5, m13 = m5;
         for (int dy = -6; dy <= 6; ++dy) {
             const int yy = y + dy;
             if ((unsigned)yy >= (unsigned)S) continue;
             const int o = (yy * S + x) * CPG + q;
             const int ady = dy < 0 ? -dy : dy;
-            upd(m13, H6[o]);
-            if (ady <= 4) upd(m9, H4[o]);
-            if (ady <= 2) upd(m5, H2[o]);
+            m13 = M::mx(m13, H6[o]);
+            if (ady <= 4) m9 = M::mx(m9, H4[o]);
+            if (ady <= 2) m5 = M::mx(m5, H2[o]);
         }
         T* op = img + (int64_t)px * cs + ch0 + q * EPC;
-        *(u32x4*)(op) = pack(m13);
-        *(u32x4*)(op + C) = pack(m9);
-        *(u32x4*)(op + 2 * C) = pack(m5);
+        *(u32x4*)(op) = M::dec(m13);
+        *(u32x4*)(op + C) = M::dec(m9);
+        *(u32x4*)(op + 2 * C) = M::dec(m5);
     }
 }
 
