@@ -1,12 +1,14 @@
 """ORACLE (test infrastructure, not product code): NumPy restatement of the reference's head decode and
 class-aware NMS.
 
-PARITY UNPINNED (see oracle/forward.py): no reference golden vectors exist and TensorFlow is not
-importable here.  `tf.image.combined_non_max_suppression` lives in un-vendored TensorFlow (only
-version evidence: `tf.__version__ == '2.2.0'` in notebook/Inference.ipynb cell 0); its published CPU
-algorithm (tensorflow/core/kernels/non_max_suppression_op.cc, BatchedNonMaxSuppressionOp) is restated
-below from its documented behaviour, anchored on the reference's only call site
-`custom_layers.py:290-297`.
+PARITY: `get_boxes` / `yolov4_head` / the `nms` wrapper are PINNED to the reference's own code -- `tests/golden/
+make_ref_fixtures.py` executes /root/reference/custom_layers.py:201-298 unmodified under a torch-backed TensorFlow
+stand-in and `tests/test_ref_fixtures.py` compares (decode to one ulp, NMS outputs identical).  UNPINNED:
+`tf.image.combined_non_max_suppression` itself, which lives in un-vendored TensorFlow (only version evidence:
+`tf.__version__ == '2.2.0'` in notebook/Inference.ipynb cell 0); its published CPU algorithm
+(tensorflow/core/kernels/non_max_suppression_op.cc, BatchedNonMaxSuppressionOp) is restated below from its documented
+behaviour, anchored on the reference's only call site `custom_layers.py:290-297`, and cross-checked against two other
+independent writings of the same semantics (the stand-in's, and the brute force of tests/test_oracle_crosscheck.py).
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this module.
 

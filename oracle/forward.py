@@ -1,9 +1,14 @@
 """ORACLE (test infrastructure, not product code): CPU restatement of the reference's forward graph.
 
-PARITY UNPINNED: the reference (taipingeric/yolo-v4-tf.keras) has no tests, golden vectors or fixtures
-for this path, and TensorFlow cannot be imported in the build container, so this restatement could not
-be checked against outputs of the reference itself.  It is written line by line from the cited
-reference lines plus the tf.keras op semantics listed in SURVEY.md §3.4.
+PARITY: PINNED TO THE REFERENCE'S OWN GRAPH CODE, UNPINNED AT THE TENSORFLOW-KERNEL LEVEL.  The reference
+(taipingeric/yolo-v4-tf.keras) has no tests, golden vectors or fixtures, and TensorFlow cannot be imported in the build
+container.  What pins this restatement: `tests/golden/make_ref_fixtures.py` runs the reference's unmodified
+`Yolov4.build_model` -> `yolov4_neck` (+ `load_weights`) from /root/reference with `tensorflow` replaced by a torch-backed
+stand-in (`tests/golden/tf_standin.py`), and `tests/test_ref_fixtures.py` holds this module to those outputs (raw heads
+within 2e-4) and `yolo4hip.plan` to the traced layer graph.  So layer order, wiring, concat orders, activations, padding,
+BN row order and weight layout are the reference's; the per-op arithmetic (Conv2D, BatchNormalization eps 1e-3, pooling
+...) follows the documented tf.keras semantics of SURVEY.md section 3.4 on both sides and was never compared with a real
+TensorFlow build.
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this module.
 

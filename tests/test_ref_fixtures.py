@@ -1,0 +1,190 @@
+"""The restatements (oracle/, yolo4hip host code) against fixtures produced by the REFERENCE'S OWN PYTHON.
+
+`tests/golden/ref_fixture.json` / `ref_416_bccd.npz` were written in the build container by
+`tests/golden/make_ref_fixtures.py`, which imports /root/reference unmodified and runs `Yolov4.__init__ / build_model`,
+`yolov4_neck / yolov4_head / nms`, `load_weights`, `get_detection_data`, `voc_ap`, `export_gt / export_prediction /
+eval_map` with `tensorflow` replaced by `tests/golden/tf_standin.py` (the op arithmetic is the stand-in's, the graph /
+order / formulas / file handling are the reference's) -- see that generator's docstring.  Nothing here reads
+/root/reference: inputs are regenerated from the seeds recorded in the fixture.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import CLASS_DIR, GOLDEN, randomize_bn
+
+FX = json.load(open(os.path.join(GOLDEN, "ref_fixture.json")))
+SEED, SIZE, NCLS = FX["seed"], FX["img_size"], FX["num_classes"]
+
+
+def ramp_checksum(a):
+    flat = np.asarray(a, dtype=np.float64).reshape(-1)
+    return float((flat * ((np.arange(flat.size) % 251) + 1)).sum())
+
+
+@pytest.fixture(scope="module")
+def weight_set():
+    from yolo4hip import weights as W
+    from yolo4hip.plan import build_plan
+    ws = randomize_bn(W.synth_weights(build_plan(SIZE, NCLS), SEED), SEED)
+    assert ramp_checksum(W.flatten(ws)[::97]) == pytest.approx(FX["weights_stream_checksum"], rel=1e-12), \
+        "the seeded weight stream drifted from the one the fixture was generated with: regenerate the fixture"
+    return ws
+
+
+def test_config_is_the_references_dict():
+    """reference config.py:1-17, as imported."""
+    from yolo4hip.config import yolo_config
+    ref = FX["yolo_config"]
+    ours = json.loads(json.dumps(yolo_config))
+    assert ours == ref
+    a = FX["attributes"]                       # what Yolov4.__init__ derives from it (models.py:25-37)
+    assert a["anchors"] == np.array(yolo_config["anchors"]).reshape((3, 3, 2)).tolist()
+    assert a["output_sizes"] == [yolo_config["img_size"][0] // s for s in yolo_config["strides"]]
+    assert a["class_names"] == [l.strip() for l in open(os.path.join(CLASS_DIR, FX["class_file"]))]
+
+
+def test_plan_is_the_graph_the_reference_builds():
+    """Every Conv2D / Add / Concatenate / MaxPooling2D / UpSampling2D the reference created (custom_layers.py:100-198),
+    in creation order with its wiring, equals yolo4hip.plan.build_plan op for op."""
+    from yolo4hip.plan import ACT_NAMES, build_plan
+    plan = build_plan(SIZE, NCLS)
+    topo = FX["topology"]
+    assert len(topo["ops"]) == len(plan.ops)
+    rename, counters = {"input": "input"}, {}
+    for ref_op, op in zip(topo["ops"], plan.ops):
+        assert ref_op["kind"] == op.kind, (ref_op, op)
+        rename[op.dst] = ref_op["dst"]
+        assert [rename[s] for s in op.srcs] == ref_op["srcs"], (ref_op, op)          # incl. the ORDER of concat inputs
+        if op.kind == "conv":
+            c = plan.convs[op.conv]
+            assert ref_op["dst"] == f"c{c.idx}" and ref_op["layer"] == ("conv2d" if c.idx == 0 else f"conv2d_{c.idx}")
+            assert (ref_op["k"], ref_op["strides"], ref_op["cin"], ref_op["cout"]) == (c.k, c.s, c.cin, c.cout)
+            assert (ref_op["in_side"], ref_op["out_side"]) == (c.in_side, c.out_side)
+            assert ref_op["act"] == ACT_NAMES[c.act] and ref_op["bn"] == c.bn and ref_op["use_bias"] == (not c.bn)
+            if c.s == 2:        # ZeroPadding2D(((1,0),(1,0))) + 'valid' (custom_layers.py:9-12)
+                assert ref_op["zero_pad"] == [[1, 0], [1, 0]] and ref_op["padding"] == "valid"
+            else:
+                assert ref_op["zero_pad"] is None and ref_op["padding"] == "same"
+            if c.bn:            # BN layer index = conv index - head convs before it (utils.py:18,34); Keras eps
+                n_heads_before = sum(1 for h in (93, 101, 109) if h < c.idx)
+                k = c.idx - n_heads_before
+                assert ref_op["bn_layer"] == ("batch_normalization" if k == 0 else f"batch_normalization_{k}")
+                assert ref_op["bn_eps"] == 1e-3
+            if ref_op["act"] == "leaky":
+                assert ref_op["alpha"] == 0.1
+        elif op.kind == "maxpool":
+            assert (ref_op["k"], ref_op["strides"], ref_op["padding"]) == (op.k, 1, "same")
+        elif op.kind == "upsample":
+            assert ref_op["size"] == [2, 2]
+        elif op.kind == "concat":
+            assert ref_op["axis"] == -1
+    assert [rename[h] for h in plan.heads] == topo["heads"] == ["c93", "c101", "c109"]
+
+
+def test_darknet_reader_matches_reference_load_weights(weight_set, tmp_path):
+    """What `utils.load_weights` (utils.py:12-53) put into each Keras layer from the Darknet file == what
+    weights.read_darknet yields, layer by layer: HWIO kernel, [gamma, beta, mean, var] rows, head biases."""
+    from yolo4hip import weights as W
+    from yolo4hip.plan import build_plan
+    plan = build_plan(SIZE, NCLS)
+    path = str(tmp_path / "synth.weights")
+    W.write_darknet(path, weight_set)
+    assert os.path.getsize(path) == FX["weights_file_bytes"]
+    ws, _header, unread = W.read_darknet(path, plan)
+    assert unread == 0 and "all weights read" in FX["ctor_prints"]
+    assert len(FX["loaded_layers"]) == 110
+    for cw, rec, c in zip(ws, FX["loaded_layers"], plan.convs):
+        hwio = cw.w.transpose(2, 3, 1, 0)                      # Darknet (out,in,h,w) -> Keras (h,w,in,out), utils.py:40-42
+        assert list(hwio.shape) == rec["kernel_shape_hwio"]
+        assert ramp_checksum(hwio) == pytest.approx(rec["kernel_ramp"], rel=1e-12, abs=1e-9)
+        if c.bn:
+            beta, gamma, mean, var = cw.bn                     # Darknet row order (utils.py:28)
+            for name, row in (("gamma", gamma), ("beta", beta), ("mean", mean), ("var", var)):
+                assert ramp_checksum(row) == pytest.approx(rec[name + "_ramp"], rel=1e-12, abs=1e-9), (c.idx, name)
+                assert float(row[0]) == rec[name + "_first"]
+        else:
+            assert ramp_checksum(cw.bias) == pytest.approx(rec["bias_ramp"], rel=1e-12, abs=1e-9)
+
+
+def test_oracle_forward_decode_nms_match_the_reference_graph(weight_set):
+    """oracle/forward.py and oracle/decode_nms.py against the reference's own yolov4_neck / yolov4_head / nms run on
+    the same weights and images.  Tolerances: float32 summation order through 110 layers (heads, logits of std 1.6:
+    2e-4), one ulp of the decode (boxes up to 760 px: 1.5e-4), probabilities 5e-7."""
+    from yolo4hip import weights as W
+    from yolo4hip.config import make_config
+    from oracle import forward as OF, decode_nms as OD
+    z = np.load(os.path.join(GOLDEN, "ref_416_bccd.npz"))
+    cfg = make_config(SIZE)
+    imgs = W.synth_images(2, SIZE, SEED)
+    heads = OF.yolo_model_forward(imgs, weight_set, NCLS)
+    for s in range(3):
+        ref = z[f"head{s}"]
+        assert heads[s][:1].shape == ref.shape
+        assert np.abs(heads[s][:1] - ref).max() < 2e-4, (s, np.abs(heads[s][:1] - ref).max())
+    # decode of the REFERENCE's heads: isolates get_boxes (custom_layers.py:221-258)
+    dec = OD.yolov4_head([z[f"head{s}"] for s in range(3)], NCLS, cfg["anchors"], cfg["xyscale"])
+    for s in range(3):
+        k = FX["decode_subsample"][str(s)]
+        for j, (name, tol) in enumerate((("bbox", 1.5e-4), ("obj", 5e-7), ("cls", 5e-7), ("xywh", 5e-7))):
+            got, ref = dec[4 * s + j][:, ::k, ::k], z[f"dec{s}_{name}"]
+            assert got.shape == ref.shape and np.abs(got - ref).max() <= tol, (s, name, np.abs(got - ref).max())
+    # whole inference_model.predict (models.py:68-73) on two images
+    b, sc, c, v, _ki = OD.inference_from_heads(heads, NCLS, cfg["anchors"], cfg["xyscale"], SIZE)
+    assert np.array_equal(v, z["inf_valid"]) and np.array_equal(c, z["inf_classes"])
+    assert np.abs(b - z["inf_boxes"]).max() < 1e-5 and np.abs(sc - z["inf_scores"]).max() < 2e-5
+    # nms with run-time thresholds (predict_nonms, models.py:516-529) on the reference's heads
+    b, sc, c, v, _ki = OD.inference_from_heads([z[f"head{s}"] for s in range(3)], NCLS, cfg["anchors"], cfg["xyscale"], SIZE,
+                                               iou_threshold=0.5, score_threshold=0.1)
+    assert np.array_equal(v, z["nonms_valid"]) and np.array_equal(c, z["nonms_classes"])
+    assert np.abs(b - z["nonms_boxes"]).max() < 1e-6 and np.abs(sc - z["nonms_scores"]).max() < 1e-6
+    assert FX["nms_print"] == "nms iou: 0.5 score: 0.1\n"
+
+
+def test_get_detection_data_matches_reference(capsys):
+    """reference utils.py:56-78 run on the reference's own inference outputs, raw image 185x273."""
+    from yolo4hip import prepost
+    z = np.load(os.path.join(GOLDEN, "ref_416_bccd.npz"))
+    names = FX["attributes"]["class_names"]
+    df = prepost.get_detection_data(np.zeros((185, 273, 3), np.uint8),
+                                    [z["inf_boxes"], z["inf_scores"], z["inf_classes"], z["inf_valid"]], names)
+    assert capsys.readouterr().out == FX["detection_data"]["print"]
+    assert list(df.columns) == FX["detection_data"]["columns"]
+    assert [str(d) for d in df.dtypes] == FX["detection_data"]["dtypes"]
+    assert json.loads(df.to_json(orient="split"))["data"] == FX["detection_data"]["records"]
+
+
+def test_voc_ap_matches_reference():
+    from yolo4hip.evalmap import voc_ap
+    for case in FX["voc_ap"]:
+        ap, mrec, mpre = voc_ap(list(case["rec"]), list(case["prec"]))
+        assert ap == case["ap"] and mrec == case["mrec"] and mpre == case["mpre"]
+
+
+def test_export_gt_and_eval_map_match_reference(tmp_path, capsys):
+    """reference models.py:129-139 (export_gt) and :182-507 (eval_map) on the reference's own prediction files."""
+    from yolo4hip.api import Yolov4
+    from yolo4hip.evalmap import eval_map
+    dirs = {k: tmp_path / k for k in ("gt", "pred", "json", "out")}
+    for d in dirs.values():
+        d.mkdir()
+    ann = tmp_path / "ann.txt"
+    ann.write_text(FX["annotation_file"])
+    facade = Yolov4.__new__(Yolov4)                    # export_gt needs only class_names (no engine, no GPU)
+    facade.class_names = FX["attributes"]["class_names"]
+    facade.export_gt(str(ann), str(dirs["gt"]))
+    assert {f: (dirs["gt"] / f).read_text() for f in sorted(os.listdir(dirs["gt"]))} == FX["gt_files"]
+    for name, text in FX["pred_files"].items():
+        (dirs["pred"] / name).write_text(text)
+    capsys.readouterr()
+    res = eval_map(str(dirs["gt"]), str(dirs["pred"]), str(dirs["json"]), str(dirs["out"]))
+    out = capsys.readouterr().out
+    ref_prints = FX["eval_map"]["prints"]
+    cut = ref_prints.index("mAP = ") + len(ref_prints[ref_prints.index("mAP = "):].splitlines()[0]) + 1
+    assert out == ref_prints[:cut]                     # the rest of the reference's prints are draw_plot_func's (display)
+    assert (dirs["out"] / "output.txt").read_text() == FX["eval_map"]["output_txt"]
+    got_json = {f: json.load(open(dirs["json"] / f)) for f in sorted(os.listdir(dirs["json"]))}
+    assert got_json == FX["eval_map"]["json"]
+    assert "mAP = {0:.2f}%".format(res["mAP"] * 100) in FX["eval_map"]["output_txt"]

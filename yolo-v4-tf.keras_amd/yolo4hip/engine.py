@@ -131,18 +131,27 @@ class Engine:
 
     # ---------------------------------------------------------------- compute
     def _to_device_images(self, imgs):
-        """array-like [N,H,W,3] any float dtype (Keras casts to float32) -> contiguous cuda float32; a uint8 torch
-        tensor (frames at network size before the /255, e.g. from `preprocess_u8`) stays uint8."""
+        """array-like [N,H,W,3] any float dtype (Keras casts to float32) -> contiguous cuda float32.  uint8 input -- a
+        torch tensor OR a numpy array, the container must not change the meaning -- is "frames at network size before the
+        /255" (what `preprocess_u8` returns, also after a `.cpu().numpy()` round trip): it stays uint8 and the stem
+        divides inside its operand load.  Other integer dtypes are refused: their scale would be a guess."""
         torch = self.torch
         if isinstance(imgs, torch.Tensor) and imgs.dtype == torch.uint8:
             t = imgs.to(self.device)                        # network-size uint8 frames: the stem divides by 255
         elif isinstance(imgs, torch.Tensor):
+            if not imgs.dtype.is_floating_point:
+                raise ValueError(f"images must be floating point in [0,1] or uint8 frames, got {imgs.dtype}")
             t = imgs.to(self.device, dtype=torch.float32)
         else:
             a = np.asarray(imgs)
-            if a.dtype != np.float32:
-                a = a.astype(np.float32)
-            t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            if a.dtype == np.uint8:
+                t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            elif a.dtype.kind != "f":
+                raise ValueError(f"images must be floating point in [0,1] or uint8 frames, got {a.dtype}")
+            else:
+                if a.dtype != np.float32:
+                    a = a.astype(np.float32)
+                t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
         if t.dim() != 4 or t.shape[1] != self.img_size or t.shape[2] != self.img_size or t.shape[3] != 3:
             raise ValueError(f"expected images of shape [N,{self.img_size},{self.img_size},3], got {tuple(t.shape)}")
         return t.contiguous()

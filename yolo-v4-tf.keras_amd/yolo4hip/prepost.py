@@ -77,20 +77,22 @@ def preprocess_img(img, img_size):
 
 
 def get_detection_data(img, model_outputs, class_names):
-    """reference utils.py:56-78 (batch element 0 only, :65-66; int64 truncation, :70-71)."""
+    """The DataFrame `predict` returns (contract of reference utils.py:56-78, pinned by tests/test_ref_fixtures.py against
+    the reference's own function): batch element 0 only, the first `valid` rows; x scaled by the raw width and y by the raw
+    height, truncated to int64; columns x1 y1 x2 y2 class_name score w h; prints the box count."""
     import pandas as pd
-    num_bboxes = int(model_outputs[-1][0])
-    boxes, scores, classes = [output[0][:num_bboxes] for output in model_outputs[:-1]]
-    h, w = img.shape[:2]
-    df = pd.DataFrame(boxes, columns=['x1', 'y1', 'x2', 'y2'])
-    df[['x1', 'x2']] = (df[['x1', 'x2']] * w).astype('int64')
-    df[['y1', 'y2']] = (df[['y1', 'y2']] * h).astype('int64')
-    df['class_name'] = np.array(class_names)[classes.astype('int64')]
-    df['score'] = scores
-    df['w'] = df['x2'] - df['x1']
-    df['h'] = df['y2'] - df['y1']
-    print(f'# of bboxes: {num_bboxes}')
-    return df
+    boxes_all, scores_all, classes_all, valid = model_outputs
+    n = valid[0]
+    raw_h, raw_w = img.shape[:2]
+    table = pd.DataFrame(boxes_all[0][:n], columns=['x1', 'y1', 'x2', 'y2'])
+    for cols, extent in ((['x1', 'x2'], raw_w), (['y1', 'y2'], raw_h)):
+        table[cols] = (table[cols] * extent).astype('int64')
+    table['class_name'] = np.array(class_names)[classes_all[0][:n].astype('int64')]
+    table['score'] = scores_all[0][:n]
+    table['w'] = table['x2'] - table['x1']
+    table['h'] = table['y2'] - table['y1']
+    print(f'# of bboxes: {n}')
+    return table
 
 
 def draw_bbox(img, detections, cmap, random_color=True, figsize=(10, 10), show_img=True, show_text=True):
