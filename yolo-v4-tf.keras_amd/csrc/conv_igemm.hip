@@ -11,6 +11,15 @@ int conv_launch_f16(int tile, const ConvK& k, hipStream_t s);
 int conv_launch_bf16_fused(int tile, const ConvK& k, hipStream_t s);
 int conv_launch_f16_fused(int tile, const ConvK& k, hipStream_t s);
 
+int conv_p8_launch_bf16(int bm, int nst, const ConvK& k, hipStream_t s);
+int conv_p8_launch_f16(int bm, int nst, const ConvK& k, hipStream_t s);
+int conv_p8_launch(int dtype, int bm, int nst, const ConvK& k, hipStream_t s) {
+    if (dtype == Y4_BF16) return conv_p8_launch_bf16(bm, nst, k, s);
+    if (dtype == Y4_F16) return conv_p8_launch_f16(bm, nst, k, s);
+    set_error("conv2d: the phased kernel is 16-bit only");
+    return Y4_EINVAL;
+}
+
 int conv_tile_count() { return kNumTiles; }
 
 static bool tile_ok(const TileCfg& tc, int dtype, int cin, int cout_pad) {

@@ -517,6 +517,9 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
     return Y4_OK;
 }
 
+// the phased kernel (conv_p8_kernel.h) lives in its own translation units (conv_p8_<dt>.hip)
+int conv_p8_launch(int dtype, int bm, int nst, const ConvK& k, hipStream_t s);
+
 // plain tiles of one dtype (one translation unit per dtype: conv_igemm_<dt>.hip)
 template <int DT>
 static int launch_plain(int tile, const ConvK& k, hipStream_t s) {
@@ -525,6 +528,7 @@ static int launch_plain(int tile, const ConvK& k, hipStream_t s) {
     case id:                                                                                  \
         if constexpr (DT == Y4_F32 && (id > F32_TILES)) break;                                \
         else if constexpr (DT == Y4_F32 && nst == 32) break;                                  \
+        else if constexpr (nst == 8 || nst == 9 || nst == 10 || nst == 40 || nst == 41) return conv_p8_launch(DT, bm, nst, k, s); \
         else return launch_cfg<DT, bm, bn, wm, wn, bkb, nst>(k, s);
     switch (tile) { Y4_TILES(Y4_TILE_CASE) }
     set_error("conv2d: tile id %d is not available for this dtype", tile);
