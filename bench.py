@@ -37,8 +37,21 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense, /opt
 METRIC = "images/sec end-to-end predict() at 608x608 batch 32; conv MFMA %peak"
 
 
-def cpu_baseline(size, ncls, ws, cfg, sample_n=8, runs=3):
-    """Oracle (kind 'port') on the host cores: forward + decode + NMS of `sample_n` images."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            models = [ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")]
+        sockets = len({ln for ln in open("/proc/cpuinfo") if ln.startswith("physical id")}) or 1
+        return f"{sockets} x {models[0]}" if models else "unknown", len(models)
+    except OSError:
+        return "unknown", os.cpu_count() or 0
+
+
+def cpu_baseline(size, ncls, ws, cfg, budget_s=10.0):
+    """the reference's tf.keras CPU predict() cannot run anywhere we run (no TensorFlow), so the figure
+    beside the GPU number is a PROXY -- the oracle (torch-CPU fp32 / oneDNN forward + NumPy decode/NMS, kind 'port') on the
+    GPU box's host cores: batch 1, and the largest batch <= 32 whose 1 warm-up + 3 timed runs fit ~`budget_s` seconds
+    (estimated from the batch-1 time; batch 32 itself needs > 10 s per run on these hosts and is reported only if it fits)."""
     import torch
     from yolo4hip import weights as W
     from oracle import forward as OF, decode_nms as OD
@@ -46,44 +59,64 @@ def cpu_baseline(size, ncls, ws, cfg, sample_n=8, runs=3):
     # threads (3.9 img/s) and collapses when every hardware thread is used (0.02 img/s at 256)
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    imgs = W.synth_images(sample_n, size, seed=0)
-    def once():
-        heads = OF.yolo_model_forward(imgs, ws, ncls)
-        return OD.inference_from_heads(heads, ncls, cfg["anchors"], cfg["xyscale"], size)
-    once()                                    # warm-up (oneDNN primitive creation, page-in)
-    t0 = time.perf_counter()
-    for _ in range(runs):
-        once()
-    dt = time.perf_counter() - t0
-    return {"value": round(sample_n * runs / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{runs} runs x {sample_n} images {size}x{size}x3, {ncls} classes, fp32 torch-CPU(oneDNN) forward "
-                      f"+ NumPy decode/NMS (oracle/), after 1 warm-up run; {dt:.1f} s of CPU work"}
+    model, hw_threads = cpu_model()
+
+    def timed(nimg, runs):
+        imgs = W.synth_images(nimg, size, seed=0)
+        def once():
+            heads = OF.yolo_model_forward(imgs, ws, ncls)
+            return OD.inference_from_heads(heads, ncls, cfg["anchors"], cfg["xyscale"], size)
+        once()                                # warm-up (oneDNN primitive creation, page-in)
+        t0 = time.perf_counter()
+        for _ in range(runs):
+            once()
+        return time.perf_counter() - t0
+    dt1 = timed(1, 3)
+    per_img = dt1 / 3
+    nb = max(2, min(32, int(budget_s / (4 * per_img * 0.6))))      # batches amortise: ~0.6x the batch-1 cost per image
+    dtb = timed(nb, 3)
+    return {"value": round(nb * 3 / dtb, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "label": "CPU restatement (proxy for tf.keras CPU; the reference's own CPU path needs TensorFlow, absent here)",
+            "cpu_model": model, "hw_threads": hw_threads,
+            "batch": nb, "batch1_value": round(3 / dt1, 4),
+            "sample": f"3 runs x {nb} images (and 3 x 1 image) {size}x{size}x3, {ncls} classes, fp32 torch-CPU(oneDNN) forward "
+                      f"+ NumPy decode/NMS (oracle/), 1 warm-up run each; {dtb + dt1:.1f} s of timed CPU work on {cores} threads"}
 
 
-def committed_traffic(args, fused_stem, chained, staged):
+def committed_traffic(args, fused_stem, chained, staged, res_mask, tiles):
     """HBM bytes per STEP of the conv kernel family from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes), or (None, reason) when this
-    run's configuration is not the profiled one.  Counters cannot be read from inside the process: the figure is NOT
-    measured by this run, `traffic_source` says where it comes from."""
-    for rnd in ("r02", "r01"):
-        path = os.path.join(ROOT, "profiles", rnd, "hbm_traffic.json" if rnd != "r01" else "hbm_traffic_v3.json")
+    run's schedule is not the profiled one: same shape, dtype and fusion switches, same residual-block mask, and the same
+    per-layer tile ids as the profiled run (`tiles.json` next to the profile).  Counters cannot be read from inside the
+    process: the figure is NOT measured by this run, `traffic_source` says where it comes from."""
+    reasons = []
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", rnd, "hbm_traffic.json")
         try:
             prof = json.load(open(path))
         except (OSError, ValueError):
             continue
         want = {"size": args.size, "classes": args.classes, "batch": args.batch, "dtype": args.dtype,
-                "stem_fusion": bool(fused_stem), "chain_fusion": bool(chained)}
+                "stem_fusion": bool(fused_stem), "chain_fusion": bool(chained), "stage_fusion": bool(staged)}
         have = dict(prof.get("config", {}))
-        if "stage_fusion" in have:
-            want["stage_fusion"] = bool(staged)
-        elif staged:
-            continue                                   # profiled before the stage fusion existed
         if have != want:
+            reasons.append(f"profiles/{rnd}: profiled configuration {have} != this run's {want}")
+            continue
+        try:
+            saved = json.load(open(os.path.join(ROOT, "profiles", rnd, "tiles.json")))
+        except (OSError, ValueError):
+            saved = {}
+        if int(saved.get("res_fusion_mask", -1)) != int(res_mask):
+            reasons.append(f"profiles/{rnd}: residual-block mask {saved.get('res_fusion_mask')} != this run's {res_mask}")
+            continue
+        if tiles is None or list(saved.get("tiles", [])) != list(tiles):
+            ndiff = sum(1 for a, b in zip(saved.get("tiles", []), tiles or []) if a != b) if tiles else -1
+            reasons.append(f"profiles/{rnd}: the autotuner picked another tile / fusion set on this box "
+                           f"({ndiff} of {len(tiles or [])} layers differ from the profiled run)")
             continue
         return int(prof["conv_igemm_hbm_bytes_per_step"]), \
-            f"profiles/{rnd}/{os.path.basename(path)} (committed rocprofv3 --pmc passes of this command; not measured by this run)"
-    return None, "no committed PMC pass matches this configuration"
+            f"profiles/{rnd}/hbm_traffic.json (committed rocprofv3 --pmc passes of this command and tile set; not measured by this run)"
+    return None, "null because: " + ("; ".join(reasons) if reasons else "no committed PMC pass exists")
 
 
 def free_port():
@@ -190,6 +223,17 @@ def main():
         return W.flatten(ws_holder["ws"])
 
     D.load_weights_distributed(eng, make_flat, src=0)          # rank 0 packs, RCCL broadcast of the packed blob
+    if os.environ.get("Y4_FORCE_ADOPT") == "1":
+        # what every rank > 0 does, made testable on ONE GPU (tests/test_gpu_dist.py): a FRESH engine takes the packed bytes
+        # that travelled through the collective (here: broadcast in place, then a device copy) and adopts them --
+        # y4_adopt_packed_weights instead of y4_pack_weights -- and the bench then runs on that engine
+        eng2 = Engine(args.classes, cfg, max_batch=args.batch, dtype=args.dtype, device=f"cuda:{local_rank}")
+        D.broadcast_bytes(eng.wts, 0)
+        eng2.wts.copy_(eng.wts)
+        torch.cuda.synchronize()
+        eng2.adopt_packed()
+        eng.close()
+        eng = eng2
     lo, hi = D.shard_range(args.batch * world, rank, world)    # this rank's slice of the global batch
     imgs = torch.from_numpy(W.synth_images(hi - lo, args.size, seed=0, first_index=lo)).to(eng.device)
     flat, outs = eng.alloc_outputs_flat(hi - lo)               # five outputs in one block: ONE D2H copy per step
@@ -238,8 +282,10 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    eng.timing_begin(args.steps * args.blocks, coarse=not args.per_op)    # 7 events per step unless --per-op
-    blocks = []
+    # HIP events on the launch stream for the first min(steps * blocks, 4096) steps (the session's capacity; later steps are
+    # simply not recorded): 8 events per step unless --per-op
+    eng.timing_begin(min(args.steps * args.blocks, 4096), coarse=not args.per_op)
+    local = []
     for _ in range(args.blocks):
         D.barrier()
         torch.cuda.synchronize()
@@ -249,8 +295,11 @@ def main():
         torch.cuda.synchronize()
         D.barrier()
         torch.cuda.synchronize()
-        blocks.append(D.max_over_ranks(time.perf_counter() - t0))
+        local.append(time.perf_counter() - t0)              # nothing but the K steps between the two brackets
+    blocks = D.max_over_ranks(local)                        # one reduction, after every timed region
     ops, nrec = eng.timing_end()
+    import hashlib
+    digest = hashlib.sha256(host.numpy().tobytes()).hexdigest()     # this rank's outputs of the last step (bit-identity checks)
 
     if rank == 0:
         dt = statistics.median(blocks)
@@ -263,7 +312,19 @@ def main():
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         conv_launches = eng.conv_launches_per_step()
-        traffic, traffic_source = committed_traffic(args, fused_stem, chained, staged)
+        traffic, traffic_source = committed_traffic(args, fused_stem, chained, staged, res_mask, tiles)
+        # the other fractions of the same peak: the backbone north_star names (convs 0..71, from the coarse
+        # segment that ends behind conv 71, plus the stem), the whole forward (every conv FLOP over stem + convs + SPP), and
+        # end to end (every conv FLOP over the wall-clock step incl. decode, NMS and the results' copy to the host)
+        op_ms = dict(ops)
+        seg_names = [name for name, ms in ops if is_conv(name) and ms > 0]
+        backbone_ms = other.get("c0", 0.0) + (op_ms.get(seg_names[0], 0.0) if seg_names else 0.0)
+        if args.per_op:
+            backbone_ms = sum(ms for name, ms in ops if name.startswith("c") and all(int(i) <= 71 for i in name[1:].split("+")))
+        backbone_flops = sum(c.flops_per_image for c in plan.convs[:72]) * (hi - lo)
+        fwd_ms = conv_ms + other.get("c0", 0.0) + other.get("spp", 0.0)
+        fwd_flops = plan.flops_per_image * (hi - lo)
+        frac_of = lambda flops, ms: round(flops / (ms * 1e-3) / 1e12 / peak, 4) if ms > 0 else None
         line = {
             "metric": METRIC,
             "value": round(n_img / dt, 2), "unit": "images/sec",
@@ -277,10 +338,18 @@ def main():
                                    f"fp32 accumulate, seeded synthetic weights",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "sharding": f"batch split over {world} rank(s), no data-path collective"},
+            "outputs_sha256": digest,
             "blocks_ms_per_step": [round(b / args.steps * 1e3, 4) for b in blocks],
             "timing": f"median of {args.blocks} blocks of {args.steps} steps, each barrier+synchronize bracketed, max over ranks",
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
+                         "backbone_frac": frac_of(backbone_flops, backbone_ms),
+                         "backbone_ms_per_step": round(backbone_ms, 4),
+                         "whole_forward_frac": frac_of(fwd_flops, fwd_ms),
+                         "end_to_end_frac": round(n_img / dt * plan.flops_per_image / 1e12 / peak / world, 4),
+                         "frac_definitions": "frac: conv family FLOPs / its HIP-event time; backbone_frac: convs 0..71 (CSPDarknet53, "
+                                             "73.696 GFLOP/image at 608) / stem + conv segment up to conv 71; whole_forward_frac: all 110 "
+                                             "convs / stem + convs + SPP; end_to_end_frac: all 110 convs x images/s (per GPU) / peak",
                          "traffic": traffic, "traffic_unit": "HBM bytes per step (all launches of the family)",
                          "traffic_source": traffic_source,
                          "kernel": "conv kernel family (convs %d..109, %d launches/step%s)" %

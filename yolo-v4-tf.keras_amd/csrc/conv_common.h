@@ -107,6 +107,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
 
+// The same, and ALSO this wave's outstanding LDS reads (lgkmcnt): for a barrier behind which another wave's LDS-DMA may
+// overwrite a slot this wave has issued (but not yet consumed) ds_reads from -- the barrier then proves "read to the end"
+// by construction, not by timing (resblock.hip phase C).
+template <int N> __device__ __forceinline__ void wait_vmcnt_lgkm_then_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt_then_barrier() {
     // counted wait for this wave's own LDS-DMA loads, then the workgroup barrier; one asm statement with a
     // "memory" clobber so that neither the compiler's loads/stores nor its own waitcnt logic move across it

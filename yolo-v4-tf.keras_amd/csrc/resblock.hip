@@ -245,13 +245,15 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
                 __builtin_amdgcn_sched_barrier(0);
                 if (st + 1 < G::NSTEPS) {
                     // step st+1 has landed when only the younger steps (issued through st+3) are still in flight; the
-                    // barrier also proves every wave has read slot(st) to the end, which the next stage_w overwrites
+                    // barrier also proves every wave has read slot(st) to the end, which the next stage_w overwrites: the
+                    // wait includes lgkmcnt(0) -- the kk = 1 reads of slot(st) issued above are not consumed before mma(1),
+                    // so without it "read to the end" would hold by timing only (they have had all of mma(0) to land: free)
                     constexpr int LAST = G::NSTEPS - 1;
                     const int younger = (st + 3 < LAST ? st + 3 : LAST) - (st + 1);
                     if (RB_ABL & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (timing experiment: no barrier)
-                    else if (younger >= 2) wait_vmcnt_then_barrier<2 * G::PPW>();
-                    else if (younger == 1) wait_vmcnt_then_barrier<G::PPW>();
-                    else wait_vmcnt_then_barrier<0>();
+                    else if (younger >= 2) wait_vmcnt_lgkm_then_barrier<2 * G::PPW>();
+                    else if (younger == 1) wait_vmcnt_lgkm_then_barrier<G::PPW>();
+                    else wait_vmcnt_lgkm_then_barrier<0>();
                     if (!(RB_ABL & 4) && st + 4 < G::NSTEPS) stage_w(st + 4);
                     read_frags(0, st + 1, 0);
                     __builtin_amdgcn_sched_barrier(0);

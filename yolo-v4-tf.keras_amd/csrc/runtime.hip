@@ -519,6 +519,7 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
             const Op& last = h->ops[rr->tail];
             const int64_t per_img = (int64_t)op.in.side * op.in.side * op.in.cstride * h->es;
             const int max_n = (int)(((1ll << 31) - 1) / per_img);
+            Y4_REQUIRE(max_n >= 1, Y4_EINVAL, "residual block: one image of the input view (%lld B) exceeds the 2 GiB buffer range", (long long)per_img);
             for (int i0 = 0; i0 < n; i0 += max_n) {
                 const int cnt = n - i0 < max_n ? n - i0 : max_n;
                 if (int r = resblock_launch(h->cfg.dtype, rr->c, buf_ptr(h, op.in, img0 + i0), cnt, op.in.side, op.in.cstride, op.in.coff,
@@ -535,6 +536,7 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
             const Op& last = h->ops[h->stage_last];
             const int64_t per_img = (int64_t)op.in.side * op.in.side * op.in.cstride * h->es;
             const int max_n = (int)(((1ll << 31) - 1) / per_img);
+            Y4_REQUIRE(max_n >= 1, Y4_EINVAL, "stage kernel: one image of the input view (%lld B) exceeds the 2 GiB buffer range", (long long)per_img);
             for (int i0 = 0; i0 < n; i0 += max_n) {           // 2 GiB buffer-descriptor range: image chunks
                 const int cnt = n - i0 < max_n ? n - i0 : max_n;
                 if (int r = csp_stage_launch(h->cfg.dtype, buf_ptr(h, op.in, img0 + i0), cnt, op.in.side, op.in.cstride, op.in.coff,
@@ -891,7 +893,11 @@ static int predict_impl(y4_handle h, const void* imgs, int n, float* boxes, floa
         int seg_first = sched.empty() ? 0 : sched[0].op;
         for (size_t k = 0; k < sched.size(); ++k) {
             const bool last = k + 1 == sched.size();
-            const bool boundary = last || h->ops[sched[k + 1].op].kind != h->ops[sched[k].op].kind;
+            // coarse segments: runs of same-kind ops, and the conv family additionally cut behind conv 71 -- the end of
+            // CSPDarknet53 proper (reference custom_layers.py:124; north_star words its target on that backbone)
+            const bool boundary = last || h->ops[sched[k + 1].op].kind != h->ops[sched[k].op].kind ||
+                                  (h->ops[sched[k].op].kind == OP_CONV && h->ops[sched[k].op].conv == 71 &&
+                                   h->ops[sched[k + 1].op].conv != 71);
             if (!h->t_coarse) {
                 h->t_slot_op.push_back(sched[k].op);
             } else if (boundary) {
@@ -1015,13 +1021,15 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
             auto block = [&](bool fused) -> float {
                 if (hipEventRecord(e0, s) != hipSuccess) return -2.f;
                 for (int i = 0; i < per_round; ++i) {
+                    int r = Y4_OK;
                     if (fused) {
-                        run_op(h, h->ops[ch.head], nullptr, images_of(ch.head), s, 0, true);
+                        r = run_op(h, h->ops[ch.head], nullptr, images_of(ch.head), s, 0, true);
                     } else {
-                        run_op(h, h->ops[ch.head], nullptr, images_of(ch.head), s, 0, false);
-                        run_op(h, h->ops[ch.tail[0]], nullptr, images_of(ch.tail[0]), s, 0, false);
-                        if (ch.tail[1] >= 0) run_op(h, h->ops[ch.tail[1]], nullptr, images_of(ch.tail[1]), s, 0, false);
+                        r = run_op(h, h->ops[ch.head], nullptr, images_of(ch.head), s, 0, false);
+                        if (r == Y4_OK) r = run_op(h, h->ops[ch.tail[0]], nullptr, images_of(ch.tail[0]), s, 0, false);
+                        if (r == Y4_OK && ch.tail[1] >= 0) r = run_op(h, h->ops[ch.tail[1]], nullptr, images_of(ch.tail[1]), s, 0, false);
                     }
+                    if (r != Y4_OK) return fused ? -3.f : -4.f;      // a failed launch must not "win" with ~0 ms
                 }
                 float ms = 0.f;
                 if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
@@ -1030,13 +1038,16 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
                 return ms;
             };
             float t_fused = 0.f, t_sep = 0.f;
-            block(true); block(false);                               // one untimed block each: both start equally warm
-            for (int r = 0; r < rounds && rc == Y4_OK; ++r) {
+            bool fused_ok = block(true) >= 0.f, sep_ok = block(false) >= 0.f;   // one untimed block each: both start equally warm
+            for (int r = 0; r < rounds && rc == Y4_OK && fused_ok && sep_ok; ++r) {
                 const float a = block(true), b = block(false);
                 if (a == -2.f || b == -2.f) { rc = Y4_EHIP; break; }
+                if (a < 0.f) fused_ok = false;
+                if (b < 0.f) sep_ok = false;
                 t_fused += a; t_sep += b;
             }
-            ch.enabled = t_fused < t_sep;
+            if (!sep_ok) { rc = Y4_EINVAL; break; }                   // the plain kernels themselves fail: report it (y4_last_error)
+            ch.enabled = fused_ok && t_fused < t_sep;
         }
     // pass 3: the stage kernel (convs 2..7 in one launch) head to head against the same ops as tuned above
     if (rc == Y4_OK && h->stage_first >= 0 && h->stage_on) {
@@ -1046,7 +1057,8 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
             h->stage_enabled = fused;
             if (hipEventRecord(e0, s) != hipSuccess) return -2.f;
             for (int i = 0; i < per_round; ++i)
-                for (int oi = h->stage_first; oi <= h->stage_last; ++oi) run_op(h, h->ops[oi], nullptr, ne, s, 0, true);
+                for (int oi = h->stage_first; oi <= h->stage_last; ++oi)
+                    if (run_op(h, h->ops[oi], nullptr, ne, s, 0, true) != Y4_OK) return fused ? -3.f : -4.f;
             float ms = 0.f;
             if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
                 hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
@@ -1054,13 +1066,16 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
             return ms;
         };
         float t_fused = 0.f, t_sep = 0.f;
-        block(true); block(false);
-        for (int r = 0; r < rounds && rc == Y4_OK; ++r) {
+        bool fused_ok = block(true) >= 0.f, sep_ok = block(false) >= 0.f;
+        for (int r = 0; r < rounds && rc == Y4_OK && fused_ok && sep_ok; ++r) {
             const float a = block(true), b = block(false);
             if (a == -2.f || b == -2.f) { rc = Y4_EHIP; break; }
+            if (a < 0.f) fused_ok = false;
+            if (b < 0.f) sep_ok = false;
             t_fused += a; t_sep += b;
         }
-        h->stage_enabled = rc == Y4_OK && t_fused < t_sep;
+        if (!sep_ok && rc == Y4_OK) rc = Y4_EINVAL;
+        h->stage_enabled = rc == Y4_OK && fused_ok && t_fused < t_sep;
     }
     // pass 4: per channel group, the residual blocks as one kernel each against the same op range as tuned above
     for (int grp = 0; grp < 2 && rc == Y4_OK && h->res_on; ++grp) {
@@ -1077,7 +1092,8 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
             h->res_enabled[grp] = fused;
             if (hipEventRecord(e0, s) != hipSuccess) return -2.f;
             for (int i = 0; i < per_round; ++i)
-                for (int oi = lo; oi <= hi; ++oi) run_op(h, h->ops[oi], nullptr, ne, s, 0, true);
+                for (int oi = lo; oi <= hi; ++oi)
+                    if (run_op(h, h->ops[oi], nullptr, ne, s, 0, true) != Y4_OK) return fused ? -3.f : -4.f;
             float ms = 0.f;
             if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
                 hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
@@ -1085,17 +1101,20 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
             return ms;
         };
         float t_fused = 0.f, t_sep = 0.f;
-        block(true); block(false);
-        for (int r = 0; r < rounds && rc == Y4_OK; ++r) {
+        bool fused_ok = block(true) >= 0.f, sep_ok = block(false) >= 0.f;
+        for (int r = 0; r < rounds && rc == Y4_OK && fused_ok && sep_ok; ++r) {
             const float a = block(true), b = block(false);
             if (a == -2.f || b == -2.f) { rc = Y4_EHIP; break; }
+            if (a < 0.f) fused_ok = false;
+            if (b < 0.f) sep_ok = false;
             t_fused += a; t_sep += b;
         }
-        h->res_enabled[grp] = rc == Y4_OK && t_fused < t_sep;
+        if (!sep_ok && rc == Y4_OK) rc = Y4_EINVAL;
+        h->res_enabled[grp] = rc == Y4_OK && fused_ok && t_fused < t_sep;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (rc != Y4_OK) set_error("y4_autotune: HIP event failure");
+    if (rc == Y4_EHIP) set_error("y4_autotune: HIP event failure");     // (Y4_EINVAL: the failing launch's own message stays)
     return rc;
 }
 
@@ -1188,6 +1207,8 @@ int y4_get_res_fusion(y4_handle h) {
 int y4_set_res_fusion_mask(y4_handle h, int mask) {
     if (int r = check_handle(h)) return r;
     Y4_REQUIRE(h->cfg.dtype != Y4_F32 || mask == 0, Y4_EINVAL, "y4_set_res_fusion_mask: 16-bit dtypes only");
+    Y4_REQUIRE(mask >= 0 && mask <= 3, Y4_EINVAL, "y4_set_res_fusion_mask: mask %d (bit 0: 128-channel blocks, bit 1: 64-channel blocks)", mask);
+    Y4_REQUIRE(h->t_max_steps == 0, Y4_ESTATE, "y4_set_res_fusion_mask: a timing session is open");
     h->res_on = mask != 0;
     h->res_enabled[0] = (mask & 1) != 0;
     h->res_enabled[1] = (mask & 2) != 0;

@@ -109,14 +109,18 @@ def gather_results(outs, n_total=None):
 
 
 def max_over_ranks(value):
+    """MAX over ranks of a float or of a list of floats (element-wise; ONE all_reduce for the whole list, so that a bench
+    can time every block locally and reduce once, after its timed region)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return float(value)
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    many = isinstance(value, (list, tuple))
+    vals = [float(v) for v in value] if many else [float(value)]
+    if dist.is_available() and dist.is_initialized():
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        vals = [float(v) for v in t.cpu().tolist()]
+    return vals if many else vals[0]
 
 
 def barrier():
