@@ -156,6 +156,9 @@ def parse_args(argv):
     ap.add_argument("--no-chain-fusion", action="store_true", help="run the 3x3+Add -> 1x1 -> 1x1 runs as separate kernels")
     ap.add_argument("--no-stage-fusion", action="store_true", help="run the 304^2 CSP stage (convs 2..7) as separate kernels")
     ap.add_argument("--no-res-fusion", action="store_true", help="run the 1x1 -> 3x3+Add residual blocks of the 64/128-channel stages as separate kernels")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight per GPU (HIP streams with one activation workspace each, shared weights); "
+                         "1 = every step on one stream")
     ap.add_argument("--per-op", action="store_true", help="also print the per-op time table to stderr")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / protocol self-test on CPU (gloo, no engine, no GPU work): the line says so")
@@ -275,16 +278,29 @@ def main():
         json.dump({"size": args.size, "classes": args.classes, "batch": args.batch, "dtype": args.dtype, "tiles": tiles,
                    "stage_fusion": bool(staged), "res_fusion_mask": int(res_mask)}, open(args.save_tiles, "w"))
 
-    def step():
-        eng.predict_device(imgs, outs)
-        host.copy_(flat, non_blocking=True)                   # boxes, scores, classes, valid (+ kept) -> host, 77 KB
+    # ---- the timed region.  `--in-flight D` (default 2): step i runs on slot i % D = engine / workspace / stream / resident
+    # batch D of the rank's shard; a step is still ONE pass of the whole hot path over ONE batch of `--batch` images and
+    # every step of a block completes inside its barrier + synchronize bracket -- steps of different slots merely overlap
+    # on the GPU where one leaves compute units idle (partial last rounds, the 32-workgroup NMS, sub-one-round 19^2 layers).
+    from yolo4hip.engine import InFlight
+    depth = max(1, args.in_flight)
+    fl = InFlight(eng, depth)
+    slot_imgs = [imgs] + [imgs.clone() for _ in range(depth - 1)]
+    slot_out = [(flat, outs)] + [eng.alloc_outputs_flat(hi - lo) for _ in range(depth - 1)]
+    slot_host = [host] + [torch.empty(flat.numel(), dtype=torch.int32).pin_memory() for _ in range(depth - 1)]
+    torch.cuda.synchronize()
+    counter = [0]
 
-    for _ in range(args.warmup):
+    def step():
+        k = counter[0] % depth
+        counter[0] += 1
+        fl.submit(slot_imgs[k], slot_out[k][1], slot_host[k], slot_out[k][0])
+
+    for _ in range(max(args.warmup, depth)):
         step()
     torch.cuda.synchronize()
-    # HIP events on the launch stream for the first min(steps * blocks, 4096) steps (the session's capacity; later steps are
-    # simply not recorded): 8 events per step unless --per-op
-    eng.timing_begin(min(args.steps * args.blocks, 4096), coarse=not args.per_op)
+    if depth == 1:                                           # one stream: the events sit in the timed blocks themselves
+        eng.timing_begin(min(args.steps * args.blocks, 4096), coarse=not args.per_op)
     local = []
     for _ in range(args.blocks):
         D.barrier()
@@ -297,9 +313,26 @@ def main():
         torch.cuda.synchronize()
         local.append(time.perf_counter() - t0)              # nothing but the K steps between the two brackets
     blocks = D.max_over_ranks(local)                        # one reduction, after every timed region
-    ops, nrec = eng.timing_end()
+    same = all(torch.equal(slot_host[0], h) for h in slot_host[1:])     # every slot ran the same batch: same outputs
+    # ---- kernel-level attribution: HIP events on the launch stream need kernels that run one after the other, so the
+    # per-kernel-family times behind `roofline` / `breakdown_ms_per_step` come from a single-stream pass of the same step
+    # (`--steps` steps, right here, same engine, same tiles) when D > 1: kernels of two streams overlap and an event pair
+    # around one of them also spans its neighbour's work.  With D = 1 the events sit in the timed blocks themselves.
+    if depth == 1:
+        ops, nrec = eng.timing_end()
+        single_ms = statistics.median(blocks) / args.steps * 1e3
+    else:
+        attrib_steps = min(args.steps, 4096)
+        eng.timing_begin(attrib_steps, coarse=not args.per_op)   # 8 events per step unless --per-op
+        t0 = time.perf_counter()
+        for _ in range(attrib_steps):
+            eng.predict_device(imgs, outs)
+            host.copy_(flat, non_blocking=True)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t0) / attrib_steps * 1e3
+        ops, nrec = eng.timing_end()
     import hashlib
-    digest = hashlib.sha256(host.numpy().tobytes()).hexdigest()     # this rank's outputs of the last step (bit-identity checks)
+    digest = hashlib.sha256(host.numpy().tobytes()).hexdigest() if same else "SLOTS DIFFER"   # outputs of the last step
 
     if rank == 0:
         dt = statistics.median(blocks)
@@ -340,7 +373,11 @@ def main():
                        "sharding": f"batch split over {world} rank(s), no data-path collective"},
             "outputs_sha256": digest,
             "blocks_ms_per_step": [round(b / args.steps * 1e3, 4) for b in blocks],
-            "timing": f"median of {args.blocks} blocks of {args.steps} steps, each barrier+synchronize bracketed, max over ranks",
+            "timing": f"median of {args.blocks} blocks of {args.steps} steps, each barrier+synchronize bracketed, max over ranks; "
+                      f"{depth} batch(es) in flight per GPU (step i on HIP stream / workspace i % {depth}, shared weights)",
+            "in_flight": depth,
+            "single_stream_ms_per_step": round(single_ms, 4),
+            "single_stream_value": round(args.batch * world / (single_ms * 1e-3), 2) if world == 1 else None,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
                          "backbone_frac": frac_of(backbone_flops, backbone_ms),
@@ -357,7 +394,11 @@ def main():
                                     (", residual blocks of the %s-channel stages in resblock_kernel" %
                                      "/".join(c for b, c in ((1, "128"), (2, "64")) if res_mask & b) if res_mask else "")),
                          "flops_per_step": conv_flops, "kernel_ms_per_step": round(conv_ms, 4),
-                         "timed_steps": nrec},
+                         "timed_steps": nrec,
+                         "measured_in": "HIP events on the launch stream over %d single-stream steps run right after the timed "
+                                        "blocks in this process (kernels of overlapping streams cannot be attributed to one "
+                                        "kernel); end_to_end_frac is from the timed blocks themselves" % nrec
+                                        if depth > 1 else "HIP events on the launch stream over the timed blocks"},
             "breakdown_ms_per_step": {"conv_family": round(conv_ms, 4), ("stem_c0+c1_fused" if fused_stem else "stem_c0"): round(other.get("c0", 0.0), 4),
                                       "spp": round(other.get("spp", 0.0), 4),
                                       "decode": round(other.get("decode", 0.0), 4),

@@ -33,20 +33,34 @@ import torch.nn.functional as F
 BN_EPS = 1e-3
 
 
+def _round_storage(t, storage):
+    """Round a float32 tensor to the 16-bit storage type and back (round-to-nearest-even): what a 16-bit pipeline keeps of
+    every activation tensor."""
+    if storage is None:
+        return t
+    return t.to(torch.bfloat16 if storage == "bf16" else torch.float16).to(torch.float32)
+
+
 class _Net:
-    def __init__(self, weights, dtype, collect=None):
+    def __init__(self, weights, dtype, collect=None, storage=None):
         self.weights = weights
         self.dtype = dtype
         self.i = 0
         self.collect = set(collect or ())
         self.taps = {}
+        # storage = 'bf16' | 'f16': EMULATE the 16-bit pipeline of the HIP path on the CPU -- weights and every stored
+        # activation tensor rounded to 16 bits, fp32 accumulate / BN / activation, the residual Add inside the 3x3 conv's
+        # epilogue (one rounding of the sum), raw heads kept in float32 -- to separate what 16-bit STORAGE costs (this
+        # emulation vs the fp32 oracle) from what the kernels add on top (HIP vs this emulation).  Not a reference behaviour.
+        self.storage = storage
+        self._defer_round = False
 
     # custom_layers.py:5-31
     def conv(self, x, filters, kernel_size, downsampling=False, activation="leaky", batch_norm=True):
         cw = self.weights[self.i]
         idx = self.i
         self.i += 1
-        w = torch.from_numpy(np.ascontiguousarray(cw.w)).to(self.dtype)   # OIHW == torch layout
+        w = _round_storage(torch.from_numpy(np.ascontiguousarray(cw.w)).to(self.dtype), self.storage)   # OIHW == torch layout
         assert w.shape[0] == filters and w.shape[2] == kernel_size, (idx, w.shape, filters, kernel_size)
         assert w.shape[1] == x.shape[1], (idx, w.shape, x.shape)
         assert (cw.bn is not None) == batch_norm, idx
@@ -66,6 +80,8 @@ class _Net:
             y = y * torch.tanh(F.softplus(y))     # :6-7
         elif activation == "leaky":
             y = F.leaky_relu(y, 0.1)              # :29-30
+        if batch_norm and not self._defer_round:      # (the three head convs are stored in float32)
+            y = _round_storage(y, self.storage)
         if idx in self.collect:
             self.taps[idx] = y
         return y
@@ -73,8 +89,10 @@ class _Net:
     # custom_layers.py:34-44
     def residual_block(self, x, filters1, filters2, activation="leaky"):
         y = self.conv(x, filters1, 1, activation=activation)
+        self._defer_round = True                      # storage emulation: the sum is rounded, not the branch
         y = self.conv(y, filters2, 3, activation=activation)
-        out = x + y
+        self._defer_round = False
+        out = _round_storage(x + y, self.storage)
         if (self.i - 1) in self.collect:
             self.taps[("add", self.i - 1)] = out      # what the HIP path stores for this conv (Add fused)
         return out
@@ -167,15 +185,17 @@ class _Net:
         return [conv_sbbox, conv_mbbox, conv_lbbox]
 
 
-def yolo_model_forward(imgs_nhwc, weights, num_classes, dtype=torch.float32, collect=None, threads=None):
+def yolo_model_forward(imgs_nhwc, weights, num_classes, dtype=torch.float32, collect=None, threads=None, storage=None):
     """`yolo_model.predict(imgs)` (`models.py:50-52`): NHWC float images in [0,1] -> list of 3 NHWC
     arrays [N,H/8,W/8,3(C+5)], [N,H/16,..], [N,H/32,..] (raw logits).  With `collect=[conv idx...]`
-    also returns {idx: NHWC array of that conv's post-activation output}."""
+    also returns {idx: NHWC array of that conv's post-activation output}.  `storage` ('bf16' | 'f16'): emulate the 16-bit
+    storage pipeline (see _Net) -- a diagnostic, not a reference behaviour."""
     if threads:
         torch.set_num_threads(int(threads))
     x = torch.from_numpy(np.ascontiguousarray(imgs_nhwc)).to(dtype)      # Keras casts to float32
+    x = _round_storage(x, storage)                      # the stem's MFMA operand is 16-bit
     x = x.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
-    net = _Net(weights, dtype, collect)
+    net = _Net(weights, dtype, collect, storage)
     with torch.no_grad():
         outs = net.yolov4_neck(x, num_classes)
     assert net.i == len(weights) == 110, net.i

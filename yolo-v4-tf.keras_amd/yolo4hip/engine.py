@@ -67,6 +67,45 @@ class Engine:
         self.nout = 3 * (self.num_classes + 5)
         self.T = self.cfg.max_total
 
+    def sibling(self):
+        """A second handle on the same GPU that SHARES this engine's packed weights (read-only) and owns a second activation
+        workspace, with the same scheduling choices (fusions, tuned tiles).  Two independent batches can then be in flight
+        on two HIP streams (`InFlight`): one batch's partial last rounds, its 32-workgroup NMS and its small 19^2 layers
+        overlap the other batch's kernels.  Results are those of this engine, bit for bit."""
+        torch = self.torch
+        e = Engine.__new__(Engine)
+        e.torch, e.lib, e.config, e.device = torch, self.lib, dict(self.config), self.device
+        e.num_classes, e.max_batch, e.cfg, e.dtype, e.img_size = self.num_classes, self.max_batch, self.cfg, self.dtype, self.img_size
+        e.handle = C.c_void_p()
+        ext.check(self.lib.y4_create(C.byref(e.cfg), C.byref(e.handle)))
+        e.flops_per_image, e.num_boxes = self.flops_per_image, self.num_boxes
+        e.head_cstride, e.weight_floats = self.head_cstride, self.weight_floats
+        e.act_bytes, e.wts_bytes = self.act_bytes, self.wts_bytes
+        with torch.cuda.device(self.device):
+            e.act = torch.empty(e.act_bytes, dtype=torch.uint8, device=self.device)
+            e.wts = self.wts                                   # the SAME tensor: packed weights are never written after packing
+            ext.check(self.lib.y4_bind_workspace(e.handle, ext.ptr(e.act), e.act_bytes, ext.ptr(e.wts), e.wts_bytes))
+        e.grids, e.nout, e.T = list(self.grids), self.nout, self.T
+        e.adopt_packed()
+        sub = getattr(self, "_subbatch", None)
+        if sub:
+            e.set_subbatch(*sub)
+        if getattr(self, "stem_fusion", False):
+            e.set_stem_fusion(True)
+        if getattr(self, "chain_fusion", False):
+            e.set_chain_fusion(True)
+        if self.dtype != "f32":
+            if self.stage_fusion_active():
+                e.set_stage_fusion(True)
+            mask = self.res_fusion_mask()
+            if mask:
+                e.set_res_fusion(True)
+                e.set_res_fusion_mask(mask)
+        tiles = (C.c_int32 * 110)()
+        ext.check(self.lib.y4_get_tiles(self.handle, tiles, 110))
+        e.set_tiles(list(tiles))
+        return e
+
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle:
             self.lib.y4_destroy(self.handle)
@@ -412,6 +451,7 @@ class Engine:
         """Run convs 0..last_conv over `images` images at a time (Infinity-Cache residency of the big early
         activations); 0 turns it off.  Results are unchanged."""
         ext.check(self.lib.y4_set_subbatch(self.handle, int(images), int(last_conv)))
+        self._subbatch = (int(images), int(last_conv)) if images > 0 else None
 
     def set_stem_fusion(self, on=True):
         """Convs 0+1 as one kernel with conv 0's output kept in LDS (16-bit dtypes, img_size <= 640).  Results are
@@ -495,3 +535,39 @@ class Engine:
                                           ext.stream_ptr()))
         raw = names.raw
         return [(raw[16 * i:16 * i + 16].split(b"\0")[0].decode(), float(ms[i])) for i in range(nops.value)]
+
+
+class InFlight:
+    """`depth` batches in flight on one GPU: the engine and depth-1 siblings (shared packed weights, own activation
+    workspaces), each on its own HIP stream, used round-robin.  A batch's kernels run in order on its stream; kernels of
+    different batches overlap wherever one leaves compute units idle (partial last rounds of its tiles, the 32-workgroup
+    NMS, the sub-one-round 19^2 layers).  Measured at 608x608 / 80 classes / batch 32 / bf16: 5.57 -> 5.03 ms per batch
+    with two in flight (three: 5.11).  Outputs are bit-identical to the single-stream path (tests/test_gpu_api.py)."""
+
+    def __init__(self, engine, depth=2):
+        torch = engine.torch
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.engines = [engine] + [engine.sibling() for _ in range(depth - 1)]
+        with torch.cuda.device(engine.device):
+            self.streams = [torch.cuda.Stream(device=engine.device) for _ in range(depth)]
+        self.torch, self.depth, self._next = torch, depth, 0
+
+    def submit(self, imgs_dev, outs, host=None, flat=None):
+        """predict_device(imgs_dev, outs) on the next slot's stream (asynchronous); with `host` / `flat` the results are
+        also copied to the pinned host tensor.  The caller owns per-slot inputs / outputs: slot = call index % depth."""
+        k = self._next
+        self._next = (k + 1) % self.depth
+        with self.torch.cuda.stream(self.streams[k]):
+            self.engines[k].predict_device(imgs_dev, outs)
+            if host is not None:
+                host.copy_(flat, non_blocking=True)
+        return k
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def close(self):
+        for e in self.engines[1:]:
+            e.close()
