@@ -1,29 +1,41 @@
 #!/bin/bash
-# Collects the measurement set committed under profiles/r02 (run on the GPU box, from the repo root):
-#   rm -rf gpurun_out/r2set                 # LOCALLY first: gpurun merges into gpurun_out/
-#   gpurun --timeout 2400 -- 'bash scripts/collect_profiles.sh'
-# Produces in gpurun_out/r2set (all from ONE call on one box):
-#   bench.json + tiles.json   default bench (incl. cpu_baseline) and its tuned tile / fusion set
-#   stats/ + stats_bench.json rocprofv3 --kernel-trace --stats of the same tile set (conv rows / 7 steps must agree with
-#                             stats_bench.json's kernel_ms_per_step), gaps.json = inter-kernel gaps from that kernel trace
-#   pmc/pass*                 separate --pmc passes (kernel trace only, program straight after `--`, as the pool requires):
-#                             FETCH_SIZE | WRITE_SIZE | SQ wave-cycle breakdown + MFMA busy | GRBM_GUI_ACTIVE + LDS | L2
-#   hbm_traffic.json (scripts/pmc_summary.py), mfma_util.json + sq_wait_breakdown.json (scripts/mfma_util.py)
+# Collects the measurement set committed under profiles/r03 (run on the GPU box, from the repo root), ONCE per round:
+#   rm -rf gpurun_out/r3set                 # LOCALLY first: gpurun merges into gpurun_out/
+#   gpurun --timeout 2700 -- 'bash scripts/collect_profiles.sh'
+# Produces in gpurun_out/r3set (all from ONE call on one box):
+#   bench.json + tiles.json        the default bench (two batches in flight; incl. cpu_baseline) and its tuned tile / fusion set
+#   bench_single_stream.json       the same tile set with --in-flight 1 (HIP events inside the timed blocks)
+#   in_flight_sweep.txt            scripts/two_batches.py 1 / 2 / 3
+#   smi_idle.txt, smi_load.txt     rocm-smi clocks / power / temperature / power cap before and (sampled every 0.5 s) during a bench
+#   stats/ + stats_bench.json      rocprofv3 --kernel-trace --stats of the single-stream command (conv rows / 7 steps must agree with
+#                                  stats_bench.json's kernel_ms_per_step), gaps.json = inter-kernel gaps from that kernel trace;
+#   stats2/ + stats2_bench.json    the same of the default (two in flight) command: kernel durations there include the neighbour stream
+#   pmc/pass*                      separate --pmc passes of the single-stream command (kernel trace only, program straight after `--`)
+#   hbm_traffic.json, mfma_util.json, sq_wait_breakdown.json, pmc_kernels.json
 #   bench_cfg5.json / bench_cfg2.json   BASELINE.json configs 5 and 2
 set -x
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2set; rm -rf $O; mkdir -p $O/pmc
+O=gpurun_out/r3set; rm -rf $O; mkdir -p $O/pmc
+SMI="rocm-smi --showclocks --showpower --showtemp --showperflevel --showmaxpower"
+$SMI > $O/smi_idle.txt 2>&1
 python bench.py --save-tiles $O/tiles.json > $O/bench.json 2> $O/bench.err
-B="python3 bench.py --no-cpu-baseline --load-tiles $O/tiles.json --blocks 1"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 5 --warmup 2 > $O/stats_bench.json 2> $O/stats.err
+( for i in $(seq 1 40); do echo "== sample $i $(date +%s.%N)"; rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|mclk|Power|junction"; sleep 0.5; done ) > $O/smi_load.txt 2>&1 &
+SMIPID=$!
+python bench.py --no-cpu-baseline --load-tiles $O/tiles.json --in-flight 1 --steps 200 --blocks 5 > $O/bench_single_stream.json 2> $O/bench_single_stream.err
+wait $SMIPID
+for s in 1 2 3; do python scripts/two_batches.py $s 2>/dev/null | tail -1; done > $O/in_flight_sweep.txt
+B1="python3 bench.py --no-cpu-baseline --load-tiles $O/tiles.json --blocks 1 --in-flight 1"
+B2="python3 bench.py --no-cpu-baseline --load-tiles $O/tiles.json --blocks 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B1 --steps 5 --warmup 2 > $O/stats_bench.json 2> $O/stats.err
 python scripts/trace_gaps.py $(ls $O/stats/*/*kernel_trace.csv | head -1) $O/gaps.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- $B2 --steps 6 --warmup 2 > $O/stats2_bench.json 2> $O/stats2.err
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
            "GRBM_GUI_ACTIVE SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_SALU SQ_INSTS_VMEM" \
            "TCC_REQ TCC_HIT TCC_MISS"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc/pass$i -- $B --steps 3 --warmup 1 > /dev/null 2> $O/pmc/pass$i.err
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc/pass$i -- $B1 --steps 3 --warmup 1 > /dev/null 2> $O/pmc/pass$i.err
   find $O/pmc/pass$i -name "*kernel_trace.csv" -delete; find $O/pmc/pass$i -name "*agent_info.csv" -delete
 done
 python scripts/pmc_summary.py 4 $O/hbm_traffic.json $O/pmc/pass1 $O/pmc/pass2

@@ -1,6 +1,6 @@
 """Phased conv kernel (conv_p8_kernel.h) against the plain tiles, layer shapes of the 608^2 batch-32 step, random data:
 interleaved rounds in one process, median device time per launch (HIP events on the launch stream).
-usage: p8_bench.py [tile ids ...]   (default: 19 39 43 33 41 44)"""
+usage: p8_bench.py [tile ids ...]   (default: 19 39 41 42 = plain, staggered, software-pipelined, producer/consumer)"""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "yolo-v4-tf.keras_amd")); sys.path.insert(0, ROOT)
@@ -9,7 +9,7 @@ from yolo4hip import ext
 lib = ext.load()
 dev, td, did = "cuda:0", torch.bfloat16, ext.DTYPE_IDS["bf16"]
 N = int(os.environ.get("NB", "32"))
-TILES = [int(a) for a in sys.argv[1:]] or [19, 39, 43, 33, 41, 44]
+TILES = [int(a) for a in sys.argv[1:]] or [19, 39, 41, 42]
 # k, s, cin, cout, side(in), res
 SHAPES = [(3,1,256,512,38,0),(1,1,512,256,38,0),(3,1,256,256,38,1),(1,1,256,256,38,0),(3,1,512,1024,19,0),(1,1,1024,512,19,0),(3,1,512,512,19,1),
           (1,1,2048,512,19,0),(3,1,128,256,76,0),(1,1,256,256,76,0),(3,2,256,512,76,0),(3,2,512,1024,38,0)]

@@ -149,11 +149,14 @@ def test_16bit_error_is_the_storage_floor(dtype, size, ncls, n):
     """Is the 16-bit error budget above (bf16: mean |err| 0.06-0.075 on the logits) inherent to 16-bit STORAGE or a kernel
     artefact?  The oracle can emulate the storage pipeline on the CPU (oracle.forward `storage=`: weights and every stored
     activation rounded to 16 bits, everything else float32).  Measured and asserted:
-      floor   = |emulation - fp32 oracle|   ~ the whole budget (what rounding 110 layers of activations costs, on any hardware)
-      kernels = |HIP - emulation|           a fraction of it: left over are 1-ulp flips from the different fp32 summation
-                                            order of the MFMA tiles vs oneDNN, which the next layers amplify like any other
-                                            rounding noise
-    The HIP path must be no further from the fp32 oracle than the emulation is (factor 1.25), i.e. it sits ON the floor."""
+      floor   = |emulation - fp32 oracle|   = the whole budget: what rounding 110 layers of activations costs on ANY hardware
+                                            (measured bf16 416/3: 0.050 / 0.057 / 0.060 per head; 608/80: 0.063 / 0.075 / 0.076;
+                                            fp16 416/3: 0.0063 / 0.0070 / 0.0075)
+      total   = |HIP - fp32 oracle|         the same numbers (0.051 / 0.057 / 0.061; 0.063 / 0.076 / 0.077; 0.0065 / 0.0073 / 0.0074)
+      kernels = |HIP - emulation|           also the same size (0.046 / 0.053 / 0.055): two 16-bit evaluations that differ in
+                                            fp32 summation order (MFMA tiles vs oneDNN) flip 1-ulp roundings, which the depth
+                                            amplifies like every other rounding -- each is as far from the other as from fp32
+    The HIP path must be no further from the fp32 oracle than the emulation is (factor 1.25): it sits ON the storage floor."""
     from oracle import forward as OF
     from yolo4hip import weights as W
     from yolo4hip.plan import build_plan

@@ -528,7 +528,7 @@ static int launch_plain(int tile, const ConvK& k, hipStream_t s) {
     case id:                                                                                  \
         if constexpr (DT == Y4_F32 && (id > F32_TILES)) break;                                \
         else if constexpr (DT == Y4_F32 && nst == 32) break;                                  \
-        else if constexpr (nst == 8 || nst == 9 || nst == 10 || nst == 40 || nst == 41) return conv_p8_launch(DT, bm, nst, k, s); \
+        else if constexpr (nst == 8 || nst == 9 || nst == 10) return conv_p8_launch(DT, bm, nst, k, s); \
         else return launch_cfg<DT, bm, bn, wm, wn, bkb, nst>(k, s);
     switch (tile) { Y4_TILES(Y4_TILE_CASE) }
     set_error("conv2d: tile id %d is not available for this dtype", tile);

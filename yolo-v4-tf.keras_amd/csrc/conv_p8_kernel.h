@@ -111,9 +111,9 @@ template <int NP> struct S9Sched {
 };
 template <int NP, int PH> __device__ __forceinline__ void s9_wait_phase() { p8_wait_vm<S9Sched<NP>::wait(PH)>(); }
 
-// M32: v_mfma_f32_32x32x16 instead of 16x16x32 (another fp32 summation order: equal to the 32x32x16 tiles of
-// conv_igemm_kernel.h bit for bit, not to the 16x16x32 ones).
-template <int DT, int BM, bool M32, int SCHED>
+// (Round 3 also built both schedules with v_mfma_f32_32x32x16: 115-117 us where the 16x16x32 forms take 96-101 -- like the
+// plain kernel's 32x32x16 tiles, DESIGN.md section 4.0 -- and removed them again.)
+template <int DT, int BM, int SCHED>
 __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
     static_assert(SCHED == 8 || SCHED == 9, "8: staggered wave groups, 9: software-pipelined");
     static_assert(DT != Y4_F32, "16-bit dtypes");
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
     // ---- staging set-up.  This thread copies chunk slot q of LDS row r0 of every 64-row part.  Pixel part j holds the rows
     // phase j reads: LDS row j*64 + w*32 + i  <-  pixel row w*WPX + j*32 + i of the tile (w = pixel half, i < 32).
     const int q = tid & 7, r0 = tid >> 3;
-    auto tswz = [](int row) { return M32 ? ((row & 7) ^ ((row >> 4) & 1)) : (row & 7); };
+    auto tswz = [](int row) { return row & 7; };
     int a_off[NP], a_mask[NP];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
@@ -164,14 +164,8 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
     for (int j = 0; j < 4; ++j) {
         const int row = r0 + j * 64;
         const int wb = row >> 6, pr = row & 63;
-        int ch;
-        if constexpr (M32) {
-            const int jb = pr >> 5, R = pr & 31, g = R >> 3, hh = (R >> 2) & 1, jj = R & 3;
-            ch = chunk_channel_g<2>(n0 + wb * WCH, 2 * jb + (g >> 1), hh) + (g & 1) * 4 + jj;
-        } else {
-            const int jn = pr >> 4, i = pr & 15, g = i >> 2, r = i & 3;
-            ch = chunk_channel(n0 + wb * WCH, jn >> 1, g) + (jn & 1) * 4 + r;
-        }
+        const int jn = pr >> 4, i = pr & 15, g = i >> 2, r = i & 3;
+        const int ch = chunk_channel(n0 + wb * WCH, jn >> 1, g) + (jn & 1) * 4 + r;
         b_vo[j] = (ch * p.K + ((q ^ tswz(row)) * EPC)) * ES;
     }
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
@@ -239,7 +233,7 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
         }
         p8_wait_vm<S9::prologue_loads() - 5>();    // K-tile 0's pixel part 0 and weights have landed
         p8_barrier();
-        if constexpr (!M32) {
+        {
             const int frow = lane & 15, fg = lane >> 4;
             int xo[2];
 #pragma unroll
@@ -300,65 +294,6 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
                 if constexpr (NP == 4) phase(std::integral_constant<int, NP - 1>{});
             }
             conv_epilogue<DT, MREP, NREP>(p, acc, m0 + wm * WPX + frow, p.M, n0 + wn * WCH, fg, full);
-        } else {
-            constexpr int MB = NP, NB = 2;
-            const int frow32 = lane & 31, fh = lane >> 5;
-            int xo[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) xo[ks] = frow32 * BKB + (((2 * ks + fh) ^ tswz(frow32)) * 16);
-            f32x16 acc[MB][NB];
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-            u32x4 wf[4][NB], xf[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                for (int j = 0; j < NB; ++j) wf[ks][j] = *(const u32x4*)(smem + rowB + j * 32 * BKB + xo[ks]);
-                xf[ks] = *(const u32x4*)(smem + rowA + xo[ks]);
-            }
-            s9_wait_phase<NP, NP - 1>();
-            p8_barrier();
-            for (int kt = 0; kt < nk; ++kt) {
-                const int st = kt & 1;
-                auto phase = [&](auto PH) {
-                    constexpr int ph = decltype(PH)::value;
-                    constexpr bool last = ph == NP - 1;
-                    const char* const na = smem + (last ? st ^ 1 : st) * STAGE + rowA + (last ? 0 : ph + 1) * PART;
-                    const char* const nb = smem + (st ^ 1) * STAGE + rowB;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                        for (int j = 0; j < NB; ++j) {
-                            const int i = ks * 2 + j;
-                            Mma32<DT>::run(acc[ph][j], wf[ks][j], xf[ks]);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (i == 0) slot_a(ph, st);
-                            if (ph == 1 && i >= 1 && i <= 4) issue_b(i - 1, st);
-                            if (j == NB - 1) xf[ks] = *(const u32x4*)(na + xo[ks]);
-                            if (last) wf[ks][j] = *(const u32x4*)(nb + j * 32 * BKB + xo[ks]);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    s9_wait_phase<NP, ph>();
-                    p8_barrier();
-                };
-                phase(std::integral_constant<int, 0>{});
-                phase(std::integral_constant<int, 1>{});
-                phase(std::integral_constant<int, 2>{});
-                if constexpr (NP == 4) phase(std::integral_constant<int, NP - 1>{});
-            }
-            f32x4 accv[MB][NB * 4];
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j)
-#pragma unroll
-                    for (int f = 0; f < 4; ++f)
-                        accv[i][j * 4 + f] = f32x4{acc[i][j][4 * f], acc[i][j][4 * f + 1], acc[i][j][4 * f + 2], acc[i][j][4 * f + 3]};
-            conv_epilogue<DT, MB, NB * 4, false, 2>(p, accv, m0 + wm * WPX + frow32, p.M, n0 + wn * WCH, fh, full);
         }
         return;
     }
@@ -387,7 +322,7 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
     p8_barrier();
     if (grp1) p8_barrier();                        // the stagger
 
-    if constexpr (!M32) {
+    {
         const int frow = lane & 15, fg = lane >> 4;
         int xo[2];
 #pragma unroll
@@ -436,69 +371,14 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
         }
         if (!grp1) p8_barrier();
         conv_epilogue<DT, MREP, NREP>(p, acc, m0 + wm * WPX + frow, p.M, n0 + wn * WCH, fg, full);
-    } else {
-        constexpr int MB = NP, NB = 2;             // 32x32 blocks of the wave tile
-        const int frow32 = lane & 31, fh = lane >> 5;
-        int xo[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) xo[ks] = frow32 * BKB + (((2 * ks + fh) ^ tswz(frow32)) * 16);
-        f32x16 acc[MB][NB];
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        u32x4 wf[4][NB];
-        for (int kt = 0; kt < nk; ++kt) {
-            const int st = kt & 1;
-            const char* const sa = smem + st * STAGE + rowA;
-            const char* const sb = smem + st * STAGE + rowB;
-#pragma unroll
-            for (int ph = 0; ph < NP; ++ph) {
-                u32x4 xf[4];
-                if (ph == 0) {
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                        for (int j = 0; j < NB; ++j) wf[ks][j] = *(const u32x4*)(sb + j * 32 * BKB + xo[ks]);
-                }
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) xf[ks] = *(const u32x4*)(sa + ph * PART + xo[ks]);
-                __builtin_amdgcn_sched_barrier(0);
-                issue(slot_region(ph), slot_late(ph) ? st ^ 1 : st);
-                if (grp1) p8_wait_phase<NP>(ph);
-                p8_barrier();
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) Mma32<DT>::run(acc[ph][j], wf[ks][j], xf[ks]);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!grp1) p8_wait_phase<NP>(ph);
-                p8_barrier();
-            }
-        }
-        if (!grp1) p8_barrier();
-        // the shared epilogue on a view of the blocks as f32x4 fragments (as the 32x32x16 tiles of conv_igemm_kernel.h)
-        f32x4 accv[MB][NB * 4];
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int f = 0; f < 4; ++f)
-                    accv[i][j * 4 + f] = f32x4{acc[i][j][4 * f], acc[i][j][4 * f + 1], acc[i][j][4 * f + 2], acc[i][j][4 * f + 3]};
-        conv_epilogue<DT, MB, NB * 4, false, 2>(p, accv, m0 + wm * WPX + frow32, p.M, n0 + wn * WCH, fh, full);
     }
 }
 
-template <int DT, int BM, bool M32, int SCHED>
+template <int DT, int BM, int SCHED>
 static int launch_p8_cfg(const ConvK& k, hipStream_t stream) {
     constexpr int lds = 2 * (BM + 256) * 128;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = conv_p8_kernel<DT, BM, M32, SCHED>;
+    auto kern = conv_p8_kernel<DT, BM, SCHED>;
     static PerDeviceOnce once;
     if (const uint64_t bit = once.due()) {
         Y4_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -509,13 +389,12 @@ static int launch_p8_cfg(const ConvK& k, hipStream_t stream) {
     return Y4_OK;
 }
 
-// nst: the schedule code of conv_tiles.h (8 / 40: staggered, 9 / 41: software-pipelined; 40 / 41: 32x32x16 MFMA)
+// nst: the schedule code of conv_tiles.h (8: staggered wave groups, 9: software-pipelined)
 template <int DT>
 static int launch_p8(int bm, int nst, const ConvK& k, hipStream_t s) {
-#define Y4_P8_CASE(BM_, NST_, M32_, SCHED_) if (bm == BM_ && nst == NST_) return launch_p8_cfg<DT, BM_, M32_, SCHED_>(k, s);
-    Y4_P8_CASE(192, 8, false, 8) Y4_P8_CASE(256, 8, false, 8) Y4_P8_CASE(192, 40, true, 8) Y4_P8_CASE(256, 40, true, 8)
-    Y4_P8_CASE(192, 9, false, 9) Y4_P8_CASE(192, 41, true, 9)
-#undef Y4_P8_CASE
+    if (bm == 192 && nst == 8) return launch_p8_cfg<DT, 192, 8>(k, s);
+    if (bm == 256 && nst == 8) return launch_p8_cfg<DT, 256, 8>(k, s);
+    if (bm == 192 && nst == 9) return launch_p8_cfg<DT, 192, 9>(k, s);
     set_error("conv2d: no phased kernel with a %d-pixel tile and schedule %d", bm, nst);
     return Y4_EINVAL;
 }

@@ -985,7 +985,7 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
         for (int tile = 1; tile <= ntiles; ++tile) {
             // the 32x32x16-MFMA tiles sum in another order than all the others: offering them here would make the outputs
             // depend on the tuner's choice.  They are measured slower anyway and stay explicit-only.
-            if (mfma32_tile(tile)) continue;
+            if (tuner_skips_tile(tile)) continue;
             op.tile = tile;
             const float ms = time_op(op, images_of(oi), false);
             if (ms == -2.f) { rc = Y4_EHIP; break; }
