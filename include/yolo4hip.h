@@ -137,6 +137,13 @@ int y4_profile(y4_handle h, const float* imgs_nhwc_dev, int n, float* op_ms, cha
  * configuration gives bit-identical outputs, so this affects speed only.  y4_get_tiles reports the choice
  * per conv index (0 = built-in heuristic). */
 int y4_autotune(y4_handle h, int n, int reps, void* stream);
+/* The same with THROUGHPUT as objective, for two batches in flight: `h2` is a second handle of the same plan (own activation
+ * workspace, may share the packed-weight workspace) that will run on `stream2` beside `h` on `stream`.  Every timed
+ * launch is issued on both handles and the time until both streams are done counts, so a tile whose last round leaves
+ * compute units idle is not charged for them (the neighbour stream fills them): the least WORK wins, not the shortest solitary
+ * launch.  Both handles end up with the same choices.  (No reference counterpart: TensorFlow's executor schedules the
+ * reference's graph; models.py:113,159.) */
+int y4_autotune_pair(y4_handle h, y4_handle h2, int n, int reps, void* stream, void* stream2);
 int y4_get_tiles(y4_handle h, int32_t* tiles, int cap);
 /* Restore a tile choice saved from y4_get_tiles (one entry per conv index; an id that does not fit its layer makes
  * the next forward fail with Y4_EINVAL rather than compute anything different). */

@@ -952,29 +952,55 @@ int y4_predict_u8(y4_handle h, const uint8_t* imgs, int n, float* boxes, float* 
 // Per-layer tile choice by measurement: every tile configuration that fits a conv is timed on the layer's
 // real shape (HIP events on `stream`, whatever data is in the workspace) and the fastest is kept.  All tiles
 // produce bit-identical results (same K order), so this changes speed only.
-int y4_autotune(y4_handle h, int n, int reps, void* stream) {
+// With a second handle `h2` (a sibling: same plan, own workspace; y4_autotune_pair) every timed launch is issued on BOTH
+// handles, each on its own stream, and the time until both streams are done is what counts: the objective becomes
+// throughput with two batches in flight -- a tile whose last round leaves compute units idle no longer pays for them (the
+// other stream fills them), so what wins is the least work, not the shortest solitary launch.  Both handles end up with
+// the same choices.
+static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t s, hipStream_t s2) {
     if (int r = check_ready(h, n)) return r;
+    if (h2)
+        if (int r = check_ready(h2, n)) return r;
     Y4_REQUIRE(reps >= 1 && reps <= 100, Y4_EINVAL, "y4_autotune: reps %d", reps);
-    hipStream_t s = (hipStream_t)stream;
-    hipEvent_t e0, e1;
+    Y4_REQUIRE(!h2 || (h2 != h && h2->ops.size() == h->ops.size() && h2->chains.size() == h->chains.size() &&
+                       h2->cfg.dtype == h->cfg.dtype && h2->S == h->S && s2 != s),
+               Y4_EINVAL, "y4_autotune_pair: the second handle must be a sibling of the first (same plan) on another stream");
+    hipEvent_t e0, e1, e2;
     Y4_CHECK_HIP(hipEventCreate(&e0));
     Y4_CHECK_HIP(hipEventCreate(&e1));
+    Y4_CHECK_HIP(hipEventCreate(&e2));
     int rc = Y4_OK;
     const int ntiles = conv_tile_count();
-    // time `reps` launches of one op; < 0: this tile does not fit, -2: HIP failure
-    auto time_op = [&](const Op& op, int ne, bool chained) -> float {
-        if (run_op(h, op, nullptr, ne, s, 0, chained) != Y4_OK) return -1.f;
-        if (hipEventRecord(e0, s) != hipSuccess) return -2.f;
-        for (int i = 0; i < reps; ++i) run_op(h, op, nullptr, ne, s, 0, chained);
-        float ms = 0.f;
-        if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
-            hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
-            return -2.f;
-        return ms;
+    // one op on the first handle, and on the second (its own stream) when there is one
+    auto run_both = [&](int oi, int ne, bool chained) -> int {
+        int r = run_op(h, h->ops[oi], nullptr, ne, s, 0, chained);
+        if (r == Y4_OK && h2) r = run_op(h2, h2->ops[oi], nullptr, ne, s2, 0, chained);
+        return r;
     };
+    // the timed region: e0 on s (s2 starts behind it), the launches, then s waits for s2's tail and e1 closes it
+    auto t_begin = [&]() -> bool {
+        if (hipEventRecord(e0, s) != hipSuccess) return false;
+        return !h2 || hipStreamWaitEvent(s2, e0, 0) == hipSuccess;
+    };
+    auto t_end = [&](float* ms) -> bool {
+        if (h2 && (hipEventRecord(e2, s2) != hipSuccess || hipStreamWaitEvent(s, e2, 0) != hipSuccess)) return false;
+        return hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+               hipEventElapsedTime(ms, e0, e1) == hipSuccess;
+    };
+    // time `reps` launches of one op; < 0: this tile does not fit, -2: HIP failure
+    auto time_op = [&](int oi, int ne, bool chained) -> float {
+        if (run_both(oi, ne, chained) != Y4_OK) return -1.f;
+        if (!t_begin()) return -2.f;
+        for (int i = 0; i < reps; ++i) run_both(oi, ne, chained);
+        float ms = 0.f;
+        return t_end(&ms) ? ms : -2.f;
+    };
+    auto set_tile = [&](int oi, int tile) { h->ops[oi].tile = tile; if (h2) h2->ops[oi].tile = tile; };
     auto images_of = [&](int oi) { return (h->sub_images > 0 && oi <= h->sub_last_op && n > h->sub_images) ? h->sub_images : n; };
-    h->stage_enabled = false;          // passes 1 and 2 tune the stage's convs as separate kernels; pass 3 decides
-    h->res_enabled[0] = h->res_enabled[1] = false;      // likewise the residual-block kernels: pass 4
+    auto set_stage = [&](bool on) { h->stage_enabled = on; if (h2) h2->stage_enabled = on; };
+    auto set_res = [&](int grp, bool on) { h->res_enabled[grp] = on; if (h2) h2->res_enabled[grp] = on; };
+    set_stage(false);                  // passes 1 and 2 tune the stage's convs as separate kernels; pass 3 decides
+    set_res(0, false); set_res(1, false);               // likewise the residual-block kernels: pass 4
     // pass 1: every conv as its own kernel
     std::vector<float> best_ms(h->ops.size(), 0.f);
     for (int oi = 0; oi < (int)h->ops.size() && rc == Y4_OK; ++oi) {
@@ -986,17 +1012,19 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
             // the 32x32x16-MFMA tiles sum in another order than all the others: offering them here would make the outputs
             // depend on the tuner's choice.  They are measured slower anyway and stay explicit-only.
             if (tuner_skips_tile(tile)) continue;
-            op.tile = tile;
-            const float ms = time_op(op, images_of(oi), false);
+            set_tile(oi, tile);
+            const float ms = time_op(oi, images_of(oi), false);
             if (ms == -2.f) { rc = Y4_EHIP; break; }
             if (ms >= 0.f && ms < best) { best = ms; best_tile = tile; }
         }
-        op.tile = best_tile;
+        set_tile(oi, best_tile);
         best_ms[oi] = best;
     }
     // pass 2: each chain as one kernel against the sum of its separate kernels
     if (h->fuse_chains)
-        for (Chain& ch : h->chains) {
+        for (size_t ci = 0; ci < h->chains.size(); ++ci) {
+            Chain& ch = h->chains[ci];
+            auto mirror = [&]() { if (h2) { h2->chains[ci].tile = ch.tile; h2->chains[ci].enabled = ch.enabled; } };
             if (rc != Y4_OK) break;
             float separate = best_ms[ch.head] + best_ms[ch.tail[0]] + (ch.tail[1] >= 0 ? best_ms[ch.tail[1]] : 0.f);
             float best = 1e30f;
@@ -1004,12 +1032,14 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
             ch.enabled = true;
             for (int tile = 1; tile <= ntiles; ++tile) {
                 ch.tile = tile;
-                const float ms = time_op(h->ops[ch.head], images_of(ch.head), true);
+                mirror();
+                const float ms = time_op(ch.head, images_of(ch.head), true);
                 if (ms == -2.f) { rc = Y4_EHIP; break; }
                 if (ms >= 0.f && ms < best) { best = ms; best_tile = tile; }
             }
             ch.tile = best_tile;
             ch.enabled = best_tile > 0;
+            mirror();
             if (!ch.enabled) continue;
             // Final decision head to head, each variant as the executor would run it: the separate kernels in their real
             // order (head, tail, tail -- not the same kernel back to back, which runs warmer than it ever does in a step)
@@ -1019,23 +1049,20 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
             (void)separate;
             const int rounds = 4, per_round = reps > 3 ? reps : 3;
             auto block = [&](bool fused) -> float {
-                if (hipEventRecord(e0, s) != hipSuccess) return -2.f;
+                if (!t_begin()) return -2.f;
                 for (int i = 0; i < per_round; ++i) {
                     int r = Y4_OK;
                     if (fused) {
-                        r = run_op(h, h->ops[ch.head], nullptr, images_of(ch.head), s, 0, true);
+                        r = run_both(ch.head, images_of(ch.head), true);
                     } else {
-                        r = run_op(h, h->ops[ch.head], nullptr, images_of(ch.head), s, 0, false);
-                        if (r == Y4_OK) r = run_op(h, h->ops[ch.tail[0]], nullptr, images_of(ch.tail[0]), s, 0, false);
-                        if (r == Y4_OK && ch.tail[1] >= 0) r = run_op(h, h->ops[ch.tail[1]], nullptr, images_of(ch.tail[1]), s, 0, false);
+                        r = run_both(ch.head, images_of(ch.head), false);
+                        if (r == Y4_OK) r = run_both(ch.tail[0], images_of(ch.tail[0]), false);
+                        if (r == Y4_OK && ch.tail[1] >= 0) r = run_both(ch.tail[1], images_of(ch.tail[1]), false);
                     }
                     if (r != Y4_OK) return fused ? -3.f : -4.f;      // a failed launch must not "win" with ~0 ms
                 }
                 float ms = 0.f;
-                if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
-                    hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
-                    return -2.f;
-                return ms;
+                return t_end(&ms) ? ms : -2.f;
             };
             float t_fused = 0.f, t_sep = 0.f;
             bool fused_ok = block(true) >= 0.f, sep_ok = block(false) >= 0.f;   // one untimed block each: both start equally warm
@@ -1048,22 +1075,20 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
             }
             if (!sep_ok) { rc = Y4_EINVAL; break; }                   // the plain kernels themselves fail: report it (y4_last_error)
             ch.enabled = fused_ok && t_fused < t_sep;
+            mirror();
         }
     // pass 3: the stage kernel (convs 2..7 in one launch) head to head against the same ops as tuned above
     if (rc == Y4_OK && h->stage_first >= 0 && h->stage_on) {
         const int ne = images_of(h->stage_first);
         const int rounds = 4, per_round = reps > 3 ? reps : 3;
         auto block = [&](bool fused) -> float {
-            h->stage_enabled = fused;
-            if (hipEventRecord(e0, s) != hipSuccess) return -2.f;
+            set_stage(fused);
+            if (!t_begin()) return -2.f;
             for (int i = 0; i < per_round; ++i)
                 for (int oi = h->stage_first; oi <= h->stage_last; ++oi)
-                    if (run_op(h, h->ops[oi], nullptr, ne, s, 0, true) != Y4_OK) return fused ? -3.f : -4.f;
+                    if (run_both(oi, ne, true) != Y4_OK) return fused ? -3.f : -4.f;
             float ms = 0.f;
-            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
-                hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
-                return -2.f;
-            return ms;
+            return t_end(&ms) ? ms : -2.f;
         };
         float t_fused = 0.f, t_sep = 0.f;
         bool fused_ok = block(true) >= 0.f, sep_ok = block(false) >= 0.f;
@@ -1075,7 +1100,7 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
             t_fused += a; t_sep += b;
         }
         if (!sep_ok && rc == Y4_OK) rc = Y4_EINVAL;
-        h->stage_enabled = rc == Y4_OK && fused_ok && t_fused < t_sep;
+        set_stage(rc == Y4_OK && fused_ok && t_fused < t_sep);
     }
     // pass 4: per channel group, the residual blocks as one kernel each against the same op range as tuned above
     for (int grp = 0; grp < 2 && rc == Y4_OK && h->res_on; ++grp) {
@@ -1089,16 +1114,13 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
         const int ne = images_of(lo);
         const int rounds = 4, per_round = reps > 3 ? reps : 3;
         auto block = [&](bool fused) -> float {
-            h->res_enabled[grp] = fused;
-            if (hipEventRecord(e0, s) != hipSuccess) return -2.f;
+            set_res(grp, fused);
+            if (!t_begin()) return -2.f;
             for (int i = 0; i < per_round; ++i)
                 for (int oi = lo; oi <= hi; ++oi)
-                    if (run_op(h, h->ops[oi], nullptr, ne, s, 0, true) != Y4_OK) return fused ? -3.f : -4.f;
+                    if (run_both(oi, ne, true) != Y4_OK) return fused ? -3.f : -4.f;
             float ms = 0.f;
-            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
-                hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
-                return -2.f;
-            return ms;
+            return t_end(&ms) ? ms : -2.f;
         };
         float t_fused = 0.f, t_sep = 0.f;
         bool fused_ok = block(true) >= 0.f, sep_ok = block(false) >= 0.f;
@@ -1110,12 +1132,20 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) {
             t_fused += a; t_sep += b;
         }
         if (!sep_ok && rc == Y4_OK) rc = Y4_EINVAL;
-        h->res_enabled[grp] = rc == Y4_OK && fused_ok && t_fused < t_sep;
+        set_res(grp, rc == Y4_OK && fused_ok && t_fused < t_sep);
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e2);
     if (rc == Y4_EHIP) set_error("y4_autotune: HIP event failure");     // (Y4_EINVAL: the failing launch's own message stays)
     return rc;
+}
+
+int y4_autotune(y4_handle h, int n, int reps, void* stream) { return autotune_impl(h, nullptr, n, reps, (hipStream_t)stream, nullptr); }
+
+int y4_autotune_pair(y4_handle h, y4_handle h2, int n, int reps, void* stream, void* stream2) {
+    if (int r = check_handle(h2)) return r;
+    return autotune_impl(h, h2, n, reps, (hipStream_t)stream, (hipStream_t)stream2);
 }
 
 int y4_set_tiles(y4_handle h, const int32_t* tiles, int count) {

@@ -87,26 +87,29 @@ class Engine:
             ext.check(self.lib.y4_bind_workspace(e.handle, ext.ptr(e.act), e.act_bytes, ext.ptr(e.wts), e.wts_bytes))
         e.grids, e.nout, e.T = list(self.grids), self.nout, self.T
         e.adopt_packed()
+        self.copy_schedule_to(e)
+        return e
+
+    def copy_schedule_to(self, e):
+        """Give engine `e` (a sibling) this engine's scheduling choices: sub-batching, fusions, tuned tiles."""
         sub = getattr(self, "_subbatch", None)
-        if sub:
-            e.set_subbatch(*sub)
-        if getattr(self, "stem_fusion", False):
-            e.set_stem_fusion(True)
-        if getattr(self, "chain_fusion", False):
-            e.set_chain_fusion(True)
+        e.set_subbatch(*(sub or (0, 16)))
         if self.dtype != "f32":
-            if self.stage_fusion_active():
-                e.set_stage_fusion(True)
+            e.set_stem_fusion(bool(getattr(self, "stem_fusion", False)))
+            e.set_chain_fusion(bool(getattr(self, "chain_fusion", False)))
+            e.set_stage_fusion(self.stage_fusion_active())
             mask = self.res_fusion_mask()
+            e.set_res_fusion(bool(mask))
             if mask:
-                e.set_res_fusion(True)
                 e.set_res_fusion_mask(mask)
         tiles = (C.c_int32 * 110)()
         ext.check(self.lib.y4_get_tiles(self.handle, tiles, 110))
         e.set_tiles(list(tiles))
-        return e
 
     def close(self):
+        for e in getattr(self, "_stream_siblings", []):
+            e.close()
+        self._stream_siblings = []
         if getattr(self, "handle", None) is not None and self.handle:
             self.lib.y4_destroy(self.handle)
             self.handle = C.c_void_p()
@@ -339,20 +342,32 @@ class Engine:
         res = [np.concatenate(p, axis=0) for p in acc]
         return res if with_indices else res[:4]
 
-    def predict_stream(self, batches, with_indices=False):
+    def predict_stream(self, batches, with_indices=False, in_flight=2):
         """Pipelined `inference_model.predict` over an iterable of uint8 batches ([n,h,w,3] numpy arrays or pinned torch
         tensors, n <= max_batch, any h,w): yields one result list per batch, in order.  A pinned tensor is uploaded from where
         it lies and may be refilled as soon as the generator yields (its upload is waited for before every yield).  While batch i computes, batch i+1 crosses PCIe as uint8
         on a second HIP stream (pinned staging, 4x fewer bytes than float32) and batch i-1's results return to the
         host, so the PCIe-inclusive rate approaches the device rate.  No float image tensor exists: frames are resized
         uint8 -> uint8 on the device when needed (`y4_resize_u8`) and the `/ 255.` happens inside the stem's operand load
-        (`y4_predict_u8`), bit-identical to `Yolov4.preprocess_img` (reference models.py:95-98) + float32 forward."""
+        (`y4_predict_u8`), bit-identical to `Yolov4.preprocess_img` (reference models.py:95-98) + float32 forward.
+        `in_flight` (default 2) batches compute at the same time, each on its own HIP stream and activation workspace
+        (`sibling()`: shared packed weights), so that one batch's idle compute units are the other's (see `InFlight`);
+        results are unchanged and still come in order."""
         torch = self.torch
         dev = self.device
         copy_stream = torch.cuda.Stream(device=dev)        # uploads
         down_stream = torch.cuda.Stream(device=dev)        # results (its own stream: it waits for the compute stream)
-        slots = [{}, {}]
-        pending = None
+        in_flight = max(1, int(in_flight))
+        sibs = getattr(self, "_stream_siblings", [])
+        while len(sibs) < in_flight - 1:
+            sibs.append(self.sibling())
+        self._stream_siblings = sibs
+        for e in sibs[:in_flight - 1]:
+            self.copy_schedule_to(e)                       # (the engine may have been re-tuned since the sibling was made)
+        engines = [self] + sibs[:in_flight - 1]
+        nslots = max(2, in_flight)
+        slots = [{} for _ in range(nslots)]
+        pending = []
 
         T, nb = self.T, self.max_batch
         # one flat int32 block per slot holds all five outputs, so that results return in ONE small D2H copy
@@ -370,13 +385,14 @@ class Engine:
             return res if with_indices else res[:4]
 
         with torch.cuda.device(dev):
-            compute = torch.cuda.current_stream()
+            cstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in engines[1:]]
             for bi, batch in enumerate(batches):
                 pinned_in = isinstance(batch, torch.Tensor) and batch.is_pinned() and batch.is_contiguous()
                 a = batch if pinned_in else np.ascontiguousarray(batch)
                 if a.dtype != (torch.uint8 if pinned_in else np.uint8) or a.ndim != 4 or a.shape[3] != 3 or not 1 <= a.shape[0] <= self.max_batch:
                     raise ValueError(f"expected uint8 [n<={self.max_batch},h,w,3] batches, got {a.dtype} {a.shape}")
-                sl = slots[bi % 2]
+                sl = slots[bi % nslots]
+                eng, compute = engines[(bi % nslots) % in_flight], cstreams[(bi % nslots) % in_flight]
                 shape = tuple(a.shape)
                 if sl.get("shape") != shape:               # (re)allocate this slot's staging for the frame geometry
                     if "done" in sl:
@@ -405,8 +421,9 @@ class Engine:
                     sl["u8"].copy_(batch if pinned_in else sl["pin"], non_blocking=True)
                     sl["up"].record(copy_stream)
                 compute.wait_event(sl["up"])
-                frames = sl["u8"] if sl["net"] is None else self.resize_u8(sl["u8"], sl["net"])
-                self.predict_device(frames[:n], tuple(t[:n] for t in sl["outs"]))
+                with torch.cuda.stream(compute):
+                    frames = sl["u8"] if sl["net"] is None else eng.resize_u8(sl["u8"], sl["net"])
+                    eng.predict_device(frames[:n], tuple(t[:n] for t in sl["outs"]))
                 sl["free"].record(compute)                 # the stem has consumed the uint8 frames
                 sl["ran"].record(compute)
                 with torch.cuda.stream(down_stream):       # results leave on a third stream: compute and uploads never wait
@@ -417,11 +434,11 @@ class Engine:
                     # the upload reads the CALLER's pinned tensor: it must have left host memory before control returns
                     # to a loader that may refill that buffer (the engine's own staging buffer is guarded by sl["free"])
                     sl["up"].synchronize()
-                if pending is not None:
-                    yield finish(pending)
-                pending = sl
-            if pending is not None:
-                yield finish(pending)
+                pending.append(sl)
+                if len(pending) >= nslots:                 # the oldest batch's slot is needed next: its results leave first
+                    yield finish(pending.pop(0))
+            while pending:
+                yield finish(pending.pop(0))
 
     def conv_output(self, conv_idx, n):
         """Dense float32 NHWC copy of conv `conv_idx`'s output from the last forward (parity tap)."""
@@ -439,6 +456,18 @@ class Engine:
         n = int(n or self.max_batch)
         with self.torch.cuda.device(self.device):
             ext.check(self.lib.y4_autotune(self.handle, n, int(reps), ext.stream_ptr()))
+        tiles = (C.c_int32 * 110)()
+        ext.check(self.lib.y4_get_tiles(self.handle, tiles, 110))
+        return list(tiles)
+
+    def autotune_pair(self, other, stream, other_stream, n=None, reps=3):
+        """`autotune` with throughput as objective, for two batches in flight (`InFlight`): every candidate is timed on this
+        engine and on its sibling `other` at once, each on its own HIP stream (y4_autotune_pair).  Both engines end up
+        with the same choices; results stay bit-identical."""
+        n = int(n or self.max_batch)
+        with self.torch.cuda.device(self.device):
+            ext.check(self.lib.y4_autotune_pair(self.handle, other.handle, n, int(reps), C.c_void_p(stream.cuda_stream),
+                                                C.c_void_p(other_stream.cuda_stream)))
         tiles = (C.c_int32 * 110)()
         ext.check(self.lib.y4_get_tiles(self.handle, tiles, 110))
         return list(tiles)
@@ -552,6 +581,19 @@ class InFlight:
         with torch.cuda.device(engine.device):
             self.streams = [torch.cuda.Stream(device=engine.device) for _ in range(depth)]
         self.torch, self.depth, self._next = torch, depth, 0
+
+    def autotune(self, n=None, reps=3):
+        """Tune engine 0 and its first sibling TOGETHER, with two batches in flight as the objective (y4_autotune_pair),
+        and copy the result to the other siblings.  Both engines need activations in their workspaces (one predict each)."""
+        torch = self.torch
+        if self.depth < 2:
+            return self.engines[0].autotune(n, reps)
+        torch.cuda.synchronize(self.engines[0].device)
+        tiles = self.engines[0].autotune_pair(self.engines[1], self.streams[0], self.streams[1], n, reps)
+        torch.cuda.synchronize(self.engines[0].device)
+        for e in self.engines[2:]:
+            self.engines[0].copy_schedule_to(e)
+        return tiles
 
     def submit(self, imgs_dev, outs, host=None, flat=None):
         """predict_device(imgs_dev, outs) on the next slot's stream (asynchronous); with `host` / `flat` the results are
