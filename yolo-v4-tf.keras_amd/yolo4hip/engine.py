@@ -365,8 +365,16 @@ class Engine:
         for e in sibs[:in_flight - 1]:
             self.copy_schedule_to(e)                       # (the engine may have been re-tuned since the sibling was made)
         engines = [self] + sibs[:in_flight - 1]
-        nslots = max(2, in_flight)
-        slots = [{} for _ in range(nslots)]
+        nslots = in_flight + 1                             # one more staging slot than computing batches: the next upload runs ahead
+        # the staging slots (pinned host buffers, device frames, output blocks, events) outlive the call: pinning tens of MB
+        # costs milliseconds, which a short stream would pay again on every call
+        cache = getattr(self, "_stream_slots", None)
+        if cache is None or len(cache) != nslots:
+            cache = self._stream_slots = [{} for _ in range(nslots)]
+        slots = cache
+        for sl in slots:
+            if "done" in sl:
+                sl["done"].synchronize()
         pending = []
 
         T, nb = self.T, self.max_batch
