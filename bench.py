@@ -148,6 +148,10 @@ def parse_args(argv):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristic instead of measuring")
     ap.add_argument("--tune-reps", type=int, default=3)
+    ap.add_argument("--tune-pair", action="store_true",
+                    help="autotune with two batches in flight as objective (y4_autotune_pair) instead of each launch alone; "
+                         "measured +0..2 %% img/s, but the chosen tiles are slower one stream at a time, which is what the "
+                         "kernel-level attribution pass (roofline.frac) times")
     ap.add_argument("--save-tiles", default=None, help="write the autotuned per-layer tile ids to this JSON file")
     ap.add_argument("--load-tiles", default=None, help="use tile ids from this JSON file instead of autotuning")
     ap.add_argument("--subbatch", type=int, default=0, help="images per sub-batch for the early layers (0 = whole batch)")
@@ -269,7 +273,7 @@ def main():
             res_mask = eng.res_fusion_mask()
     elif not args.no_autotune:
         eng.predict_device(imgs, outs)                        # real activations in the workspace
-        tune_pair = args.in_flight > 1                        # the tuner's objective is what the bench runs: D batches in flight
+        tune_pair = args.in_flight > 1 and args.tune_pair     # objective: D batches in flight instead of each launch alone
         if not tune_pair:
             tiles = eng.autotune(hi - lo, reps=args.tune_reps)    # untimed, one-off: fastest tile / fusion per layer (bit-identical results)
     else:

@@ -19,10 +19,12 @@ O=gpurun_out/r3set; rm -rf $O; mkdir -p $O/pmc
 SMI="rocm-smi --showclocks --showpower --showtemp --showperflevel --showmaxpower"
 $SMI > $O/smi_idle.txt 2>&1
 python bench.py --save-tiles $O/tiles.json > $O/bench.json 2> $O/bench.err
-( for i in $(seq 1 40); do echo "== sample $i $(date +%s.%N)"; rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|mclk|Power|junction"; sleep 0.5; done ) > $O/smi_load.txt 2>&1 &
-SMIPID=$!
-python bench.py --no-cpu-baseline --load-tiles $O/tiles.json --in-flight 1 --steps 200 --blocks 5 > $O/bench_single_stream.json 2> $O/bench_single_stream.err
-wait $SMIPID
+# steady single-stream load for ~45 s; the sampler starts once the engine is up and the steps are running
+python bench.py --no-cpu-baseline --load-tiles $O/tiles.json --in-flight 1 --steps 1500 --blocks 5 > $O/bench_single_stream.json 2> $O/bench_single_stream.err &
+BPID=$!
+sleep 22
+( for i in $(seq 1 24); do echo "== sample $i $(date +%s.%N)"; rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|mclk|Power \(W\)|junction"; sleep 0.4; done ) > $O/smi_load.txt 2>&1
+wait $BPID
 for s in 1 2 3; do python scripts/two_batches.py $s 2>/dev/null | tail -1; done > $O/in_flight_sweep.txt
 B1="python3 bench.py --no-cpu-baseline --load-tiles $O/tiles.json --blocks 1 --in-flight 1"
 B2="python3 bench.py --no-cpu-baseline --load-tiles $O/tiles.json --blocks 1"
