@@ -148,10 +148,12 @@ def parse_args(argv):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristic instead of measuring")
     ap.add_argument("--tune-reps", type=int, default=3)
-    ap.add_argument("--tune-pair", action="store_true",
-                    help="autotune with two batches in flight as objective (y4_autotune_pair) instead of each launch alone; "
-                         "measured +0..2 %% img/s, but the chosen tiles are slower one stream at a time, which is what the "
-                         "kernel-level attribution pass (roofline.frac) times")
+    ap.add_argument("--pair-passes", type=int, default=12,
+                    help="with --in-flight > 1: which autotune decisions use two batches in flight as objective (y4_autotune_pair) "
+                         "instead of one launch alone -- bit 0 tiles, 1 chains / LDS pairs, 2 stage kernel, 3 residual-block kernels. "
+                         "Default 12: the spatially tiled kernels' ragged last rounds are filled by the neighbour stream, so they "
+                         "are judged by their work (measured +2 %% img/s); tiles stay tuned per launch (their pair-tuned choice "
+                         "measured -1 %% and is 12 %% slower one stream at a time).  0 = plain y4_autotune")
     ap.add_argument("--save-tiles", default=None, help="write the autotuned per-layer tile ids to this JSON file")
     ap.add_argument("--load-tiles", default=None, help="use tile ids from this JSON file instead of autotuning")
     ap.add_argument("--subbatch", type=int, default=0, help="images per sub-batch for the early layers (0 = whole batch)")
@@ -273,7 +275,7 @@ def main():
             res_mask = eng.res_fusion_mask()
     elif not args.no_autotune:
         eng.predict_device(imgs, outs)                        # real activations in the workspace
-        tune_pair = args.in_flight > 1 and args.tune_pair     # objective: D batches in flight instead of each launch alone
+        tune_pair = args.in_flight > 1 and args.pair_passes > 0     # some decisions judged with D batches in flight
         if not tune_pair:
             tiles = eng.autotune(hi - lo, reps=args.tune_reps)    # untimed, one-off: fastest tile / fusion per layer (bit-identical results)
     else:
@@ -289,7 +291,7 @@ def main():
     fl = InFlight(eng, depth)
     if tune_pair:                                              # engine 0 and its sibling tuned TOGETHER on their two streams
         fl.engines[1].predict_device(imgs, outs)
-        tiles = fl.autotune(hi - lo, reps=args.tune_reps)
+        tiles = fl.autotune(hi - lo, reps=args.tune_reps, passes=args.pair_passes)
     if not args.no_autotune and not args.load_tiles:
         if staged:
             staged = bool(eng.stage_fusion_active())          # the tuner may have turned the stage kernel off

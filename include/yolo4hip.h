@@ -141,9 +141,11 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream);
  * workspace, may share the packed-weight workspace) that will run on `stream2` beside `h` on `stream`.  Every timed
  * launch is issued on both handles and the time until both streams are done counts, so a tile whose last round leaves
  * compute units idle is not charged for them (the neighbour stream fills them): the least WORK wins, not the shortest solitary
- * launch.  Both handles end up with the same choices.  (No reference counterpart: TensorFlow's executor schedules the
- * reference's graph; models.py:113,159.) */
-int y4_autotune_pair(y4_handle h, y4_handle h2, int n, int reps, void* stream, void* stream2);
+ * launch.  `pair_passes` says which decisions use that objective (the others are taken one launch at a time, as y4_autotune
+ * does): bit 0 the tile of every conv, bit 1 chains / LDS pairs fused or separate, bit 2 the stage kernel, bit 3 the
+ * residual-block kernels.  Both handles end up with the same choices.  (No reference counterpart: TensorFlow's executor
+ * schedules the reference's graph; models.py:113,159.) */
+int y4_autotune_pair(y4_handle h, y4_handle h2, int n, int reps, void* stream, void* stream2, int pair_passes);
 int y4_get_tiles(y4_handle h, int32_t* tiles, int cap);
 /* Restore a tile choice saved from y4_get_tiles (one entry per conv index; an id that does not fit its layer makes
  * the next forward fail with Y4_EINVAL rather than compute anything different). */

@@ -957,7 +957,7 @@ int y4_predict_u8(y4_handle h, const uint8_t* imgs, int n, float* boxes, float* 
 // throughput with two batches in flight -- a tile whose last round leaves compute units idle no longer pays for them (the
 // other stream fills them), so what wins is the least work, not the shortest solitary launch.  Both handles end up with
 // the same choices.
-static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t s, hipStream_t s2) {
+static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t s, hipStream_t s2, int pair_passes) {
     if (int r = check_ready(h, n)) return r;
     if (h2)
         if (int r = check_ready(h2, n)) return r;
@@ -971,19 +971,21 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
     Y4_CHECK_HIP(hipEventCreate(&e2));
     int rc = Y4_OK;
     const int ntiles = conv_tile_count();
-    // one op on the first handle, and on the second (its own stream) when there is one
+    // one op on the first handle, and on the second (its own stream) in the passes that use the two-stream objective
+    // (pair_passes bit 0: tiles, 1: chains / LDS pairs, 2: stage kernel, 3: residual-block kernels)
+    bool two = false;
     auto run_both = [&](int oi, int ne, bool chained) -> int {
         int r = run_op(h, h->ops[oi], nullptr, ne, s, 0, chained);
-        if (r == Y4_OK && h2) r = run_op(h2, h2->ops[oi], nullptr, ne, s2, 0, chained);
+        if (r == Y4_OK && two) r = run_op(h2, h2->ops[oi], nullptr, ne, s2, 0, chained);
         return r;
     };
     // the timed region: e0 on s (s2 starts behind it), the launches, then s waits for s2's tail and e1 closes it
     auto t_begin = [&]() -> bool {
         if (hipEventRecord(e0, s) != hipSuccess) return false;
-        return !h2 || hipStreamWaitEvent(s2, e0, 0) == hipSuccess;
+        return !two || hipStreamWaitEvent(s2, e0, 0) == hipSuccess;
     };
     auto t_end = [&](float* ms) -> bool {
-        if (h2 && (hipEventRecord(e2, s2) != hipSuccess || hipStreamWaitEvent(s, e2, 0) != hipSuccess)) return false;
+        if (two && (hipEventRecord(e2, s2) != hipSuccess || hipStreamWaitEvent(s, e2, 0) != hipSuccess)) return false;
         return hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
                hipEventElapsedTime(ms, e0, e1) == hipSuccess;
     };
@@ -1002,6 +1004,7 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
     set_stage(false);                  // passes 1 and 2 tune the stage's convs as separate kernels; pass 3 decides
     set_res(0, false); set_res(1, false);               // likewise the residual-block kernels: pass 4
     // pass 1: every conv as its own kernel
+    two = h2 && (pair_passes & 1);
     std::vector<float> best_ms(h->ops.size(), 0.f);
     for (int oi = 0; oi < (int)h->ops.size() && rc == Y4_OK; ++oi) {
         Op& op = h->ops[oi];
@@ -1021,6 +1024,7 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
         best_ms[oi] = best;
     }
     // pass 2: each chain as one kernel against the sum of its separate kernels
+    two = h2 && (pair_passes & 2);
     if (h->fuse_chains)
         for (size_t ci = 0; ci < h->chains.size(); ++ci) {
             Chain& ch = h->chains[ci];
@@ -1078,6 +1082,7 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
             mirror();
         }
     // pass 3: the stage kernel (convs 2..7 in one launch) head to head against the same ops as tuned above
+    two = h2 && (pair_passes & 4);
     if (rc == Y4_OK && h->stage_first >= 0 && h->stage_on) {
         const int ne = images_of(h->stage_first);
         const int rounds = 4, per_round = reps > 3 ? reps : 3;
@@ -1103,6 +1108,7 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
         set_stage(rc == Y4_OK && fused_ok && t_fused < t_sep);
     }
     // pass 4: per channel group, the residual blocks as one kernel each against the same op range as tuned above
+    two = h2 && (pair_passes & 8);
     for (int grp = 0; grp < 2 && rc == Y4_OK && h->res_on; ++grp) {
         int lo = -1, hi = -1;
         for (const ResRun& r : h->resruns)
@@ -1141,11 +1147,12 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
     return rc;
 }
 
-int y4_autotune(y4_handle h, int n, int reps, void* stream) { return autotune_impl(h, nullptr, n, reps, (hipStream_t)stream, nullptr); }
+int y4_autotune(y4_handle h, int n, int reps, void* stream) { return autotune_impl(h, nullptr, n, reps, (hipStream_t)stream, nullptr, 0); }
 
-int y4_autotune_pair(y4_handle h, y4_handle h2, int n, int reps, void* stream, void* stream2) {
+int y4_autotune_pair(y4_handle h, y4_handle h2, int n, int reps, void* stream, void* stream2, int pair_passes) {
     if (int r = check_handle(h2)) return r;
-    return autotune_impl(h, h2, n, reps, (hipStream_t)stream, (hipStream_t)stream2);
+    Y4_REQUIRE(pair_passes >= 0 && pair_passes <= 15, Y4_EINVAL, "y4_autotune_pair: pair_passes %d (bits 0..3)", pair_passes);
+    return autotune_impl(h, h2, n, reps, (hipStream_t)stream, (hipStream_t)stream2, pair_passes);
 }
 
 int y4_set_tiles(y4_handle h, const int32_t* tiles, int count) {

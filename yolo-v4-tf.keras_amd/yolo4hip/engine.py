@@ -468,14 +468,15 @@ class Engine:
         ext.check(self.lib.y4_get_tiles(self.handle, tiles, 110))
         return list(tiles)
 
-    def autotune_pair(self, other, stream, other_stream, n=None, reps=3):
+    def autotune_pair(self, other, stream, other_stream, n=None, reps=3, passes=15):
         """`autotune` with throughput as objective, for two batches in flight (`InFlight`): every candidate is timed on this
         engine and on its sibling `other` at once, each on its own HIP stream (y4_autotune_pair).  Both engines end up
-        with the same choices; results stay bit-identical."""
+        with the same choices; results stay bit-identical.  `passes`: which decisions use the two-stream objective -- bit 0
+        tiles, 1 chains / LDS pairs, 2 the stage kernel, 3 the residual-block kernels (the rest: one launch at a time)."""
         n = int(n or self.max_batch)
         with self.torch.cuda.device(self.device):
             ext.check(self.lib.y4_autotune_pair(self.handle, other.handle, n, int(reps), C.c_void_p(stream.cuda_stream),
-                                                C.c_void_p(other_stream.cuda_stream)))
+                                                C.c_void_p(other_stream.cuda_stream), int(passes)))
         tiles = (C.c_int32 * 110)()
         ext.check(self.lib.y4_get_tiles(self.handle, tiles, 110))
         return list(tiles)
@@ -590,14 +591,15 @@ class InFlight:
             self.streams = [torch.cuda.Stream(device=engine.device) for _ in range(depth)]
         self.torch, self.depth, self._next = torch, depth, 0
 
-    def autotune(self, n=None, reps=3):
-        """Tune engine 0 and its first sibling TOGETHER, with two batches in flight as the objective (y4_autotune_pair),
-        and copy the result to the other siblings.  Both engines need activations in their workspaces (one predict each)."""
+    def autotune(self, n=None, reps=3, passes=15):
+        """Tune engine 0 and its first sibling TOGETHER, with two batches in flight as the objective of the decisions in
+        `passes` (y4_autotune_pair), and copy the result to the other siblings.  Both engines need activations in their
+        workspaces (one predict each)."""
         torch = self.torch
         if self.depth < 2:
             return self.engines[0].autotune(n, reps)
         torch.cuda.synchronize(self.engines[0].device)
-        tiles = self.engines[0].autotune_pair(self.engines[1], self.streams[0], self.streams[1], n, reps)
+        tiles = self.engines[0].autotune_pair(self.engines[1], self.streams[0], self.streams[1], n, reps, passes)
         torch.cuda.synchronize(self.engines[0].device)
         for e in self.engines[2:]:
             self.engines[0].copy_schedule_to(e)
