@@ -110,6 +110,7 @@ class Engine:
         for e in getattr(self, "_stream_siblings", []):
             e.close()
         self._stream_siblings = []
+        self._stream_slots = None                          # predict_stream's pinned staging buffers
         if getattr(self, "handle", None) is not None and self.handle:
             self.lib.y4_destroy(self.handle)
             self.handle = C.c_void_p()
@@ -400,7 +401,7 @@ class Engine:
                 if a.dtype != (torch.uint8 if pinned_in else np.uint8) or a.ndim != 4 or a.shape[3] != 3 or not 1 <= a.shape[0] <= self.max_batch:
                     raise ValueError(f"expected uint8 [n<={self.max_batch},h,w,3] batches, got {a.dtype} {a.shape}")
                 sl = slots[bi % nslots]
-                eng, compute = engines[(bi % nslots) % in_flight], cstreams[(bi % nslots) % in_flight]
+                eng, compute = engines[bi % in_flight], cstreams[bi % in_flight]     # batches alternate engines; slots rotate on their own
                 shape = tuple(a.shape)
                 if sl.get("shape") != shape:               # (re)allocate this slot's staging for the frame geometry
                     if "done" in sl:
