@@ -188,3 +188,35 @@ def test_export_gt_and_eval_map_match_reference(tmp_path, capsys):
     got_json = {f: json.load(open(dirs["json"] / f)) for f in sorted(os.listdir(dirs["json"]))}
     assert got_json == FX["eval_map"]["json"]
     assert "mAP = {0:.2f}%".format(res["mAP"] * 100) in FX["eval_map"]["output_txt"]
+
+
+def test_oracle_matches_the_reference_graph_with_80_classes():
+    """The second reference-generated fixture: the reference's Yolov4 with coco_classes.txt (255 head channels, 5 + C = 85
+    decode stride, NMS over 80 classes) on the same 416x416 grid; heads / decoded tensors on the stored spatial sub-grid."""
+    from yolo4hip import weights as W
+    from yolo4hip.config import make_config
+    from yolo4hip.plan import build_plan
+    from oracle import forward as OF, decode_nms as OD
+    meta = FX["coco"]
+    z = np.load(os.path.join(GOLDEN, "ref_416_coco.npz"))
+    ncls, seed = meta["num_classes"], meta["seed"]
+    assert meta["head_channels"] == [3 * (ncls + 5)] * 3
+    ws = randomize_bn(W.synth_weights(build_plan(SIZE, ncls), seed), seed)
+    assert ramp_checksum(W.flatten(ws)[::97]) == pytest.approx(meta["weights_stream_checksum"], rel=1e-12)
+    cfg = make_config(SIZE)
+    imgs = W.synth_images(2, SIZE, seed)
+    heads = OF.yolo_model_forward(imgs, ws, ncls)
+    dec = OD.yolov4_head([h[:1] for h in heads], ncls, cfg["anchors"], cfg["xyscale"])
+    for s in range(3):
+        k = meta["subsample"][str(s)]
+        assert np.abs(heads[s][:1, ::k, ::k] - z[f"head{s}"]).max() < 2e-4, s
+        # (decode of the ORACLE's heads here: 1e-4 of head noise moves a 600-pixel box by < 0.1)
+        assert np.abs(dec[4 * s][:, ::k, ::k] - z[f"dec{s}_bbox"]).max() < 0.2
+        assert np.abs(dec[4 * s + 1][:, ::k, ::k] - z[f"dec{s}_obj"]).max() < 1e-4
+    assert np.abs(dec[4 * 2 + 2][:, ::2, ::2] - z["dec2_cls"]).max() < 1e-4
+    b, sc, c, v, _ki = OD.inference_from_heads(heads, ncls, cfg["anchors"], cfg["xyscale"], SIZE)
+    assert np.array_equal(v, z["inf_valid"]) and v.tolist() == meta["valid"]
+    same = c == z["inf_classes"]
+    assert same.mean() > 0.98                      # rank swaps between near-tied scores of different classes only
+    assert np.abs(np.sort(sc, axis=1) - np.sort(z["inf_scores"], axis=1)).max() < 1e-4
+    assert len(meta["classes_seen"]) > 10          # the 80-class NMS really saw many classes
