@@ -46,8 +46,10 @@ def _worker(rank, world, port, ret):
     ok_gather = ok_gather and np.array_equal(g2[0], np.arange(n_odd, dtype=np.int32)) and \
         np.array_equal(g2[1], np.arange(n_odd, dtype=np.float32).reshape(-1, 1).repeat(3, axis=1))
     mx = D.max_over_ranks(10.0 + rank)
+    # the bench's per-block times: taken locally, reduced element-wise with ONE all_reduce after the last timed block
+    mxs = D.max_over_ranks([1.0 + rank, 5.0 - rank, 3.0])
     D.barrier()
-    ret[rank] = (ok_bcast, ok_gather, mx)
+    ret[rank] = (ok_bcast, ok_gather, mx, mxs)
     torch.distributed.destroy_process_group()
 
 
@@ -58,5 +60,5 @@ def test_two_rank_gloo_protocol():
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert len(ret) == world
     for rank in range(world):
-        ok_bcast, ok_gather, mx = ret[rank]
-        assert ok_bcast and ok_gather and mx == 11.0
+        ok_bcast, ok_gather, mx, mxs = ret[rank]
+        assert ok_bcast and ok_gather and mx == 11.0 and mxs == [2.0, 5.0, 3.0]
