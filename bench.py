@@ -398,9 +398,12 @@ def main():
                          "backbone_ms_per_step": round(backbone_ms, 4),
                          "whole_forward_frac": frac_of(fwd_flops, fwd_ms),
                          "end_to_end_frac": round(n_img / dt * plan.flops_per_image / 1e12 / peak / world, 4),
+                         "timed_region_frac": round(conv_flops / (dt / args.steps) / 1e12 / peak, 4),
                          "frac_definitions": "frac: conv family FLOPs / its HIP-event time; backbone_frac: convs 0..71 (CSPDarknet53, "
                                              "73.696 GFLOP/image at 608) / stem + conv segment up to conv 71; whole_forward_frac: all 110 "
-                                             "convs / stem + convs + SPP; end_to_end_frac: all 110 convs x images/s (per GPU) / peak",
+                                             "convs / stem + convs + SPP; end_to_end_frac: all 110 convs x images/s (per GPU) / peak; timed_region_frac: the conv "
+                                             "family's FLOPs / the WALL time of a step in the timed blocks (a lower bound on the family inside the "
+                                             "timed region: that time also holds stem, SPP, decode, NMS and the copy of the results)",
                          "traffic": traffic, "traffic_unit": "HBM bytes per step (all launches of the family)",
                          "traffic_source": traffic_source,
                          "kernel": "conv kernel family (convs %d..109, %d launches/step%s)" %
