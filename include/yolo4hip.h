@@ -78,6 +78,12 @@ int y4_layer_info(y4_handle h, int idx, y4_layer_desc* out);
 int y4_model_info(y4_handle h, int64_t* flops_per_image, int32_t* num_boxes, int32_t* head_cstride,
                   int64_t* weight_floats);
 
+/* Optional, BEFORE y4_workspace_bytes / y4_bind_workspace: let activation buffers whose lifetimes do not overlap share memory
+ * (liveness over the op order, every fusable group of ops counted as one instant).  The activation workspace shrinks to about a
+ * quarter and the working set the Infinity Cache sees becomes hotter; the price: intermediate tensors are not retained after a
+ * forward (y4_get_conv_output then returns Y4_ESTATE) and sub-batching is refused.  Results are unchanged.  (Stands where
+ * TensorFlow's memory planner stands in the reference; not in tree.) */
+int y4_set_workspace_aliasing(y4_handle h, int on);
 /* Device memory the caller must provide: `act` = activations + decode/NMS scratch for max_batch images,
  * `wts` = packed weights (+ per-channel scale/shift). */
 int y4_workspace_bytes(y4_handle h, size_t* act_bytes, size_t* wts_bytes);

@@ -10,6 +10,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "conv_tiles.h"
@@ -130,6 +131,9 @@ struct y4_ctx {
     }
     // images of the current call are uint8 frames at network size (y4_forward_u8 / y4_predict_u8): the stem divides by 255
     bool img_u8 = false;
+    // activation buffers share memory when their lifetimes do not overlap (y4_set_workspace_aliasing): a quarter of the
+    // workspace, a hotter working set for the Infinity Cache; intermediate tensors are then not retained after a forward
+    bool alias_bufs = false;
 };
 
 namespace {
@@ -427,15 +431,81 @@ void find_resruns(y4_ctx& c) {
     }
 }
 
+// Lifetime of every activation buffer in op-index time, for the aliasing layout.  A buffer lives from the first op that
+// writes it to the last op that reads it; every group of ops that CAN run as one kernel (chains and LDS pairs, the stage
+// kernel, residual blocks -- whether or not the tuner enables them) counts as one instant for everything it touches, because a
+// fused kernel writes its tails' outputs while other workgroups of the same launch still read the head's inputs.  The raw
+// heads live to the end (decode reads them; y4_get_heads).
+static void buffer_lifetimes(const y4_ctx& c, std::vector<int>& first, std::vector<int>& last) {
+    const int nb = (int)c.bufs.size(), nops = (int)c.ops.size();
+    first.assign(nb, nops); last.assign(nb, -1);
+    std::vector<int> lo(nops), hi(nops);                 // the instant [lo, hi] an op belongs to
+    for (int i = 0; i < nops; ++i) lo[i] = hi[i] = i;
+    auto merge = [&](int a, int b) {                     // ops a..b are one instant (merged with whatever they already belong to)
+        int l = a, h = b;
+        for (int i = a; i <= b; ++i) { l = std::min(l, lo[i]); h = std::max(h, hi[i]); }
+        for (int i = l; i <= h; ++i) { lo[i] = std::min(lo[i], l); hi[i] = std::max(hi[i], h); }
+    };
+    for (const Chain& ch : c.chains) merge(ch.head, std::max(ch.tail[0], ch.tail[1]));
+    if (c.stage_first >= 0) merge(c.stage_first, c.stage_last);
+    for (const ResRun& r : c.resruns) merge(r.head, r.tail);
+    if (nops > 1) merge(0, 1);                           // convs 0 + 1 (stem_down)
+    for (int pass = 0; pass < 4; ++pass)                 // close the merge transitively (groups that overlap chain together)
+        for (int i = 0; i < nops; ++i) merge(lo[i], hi[i]);
+    auto touch = [&](const View& v, int i) {
+        if (v.buf < 0) return;
+        first[v.buf] = std::min(first[v.buf], lo[i]);
+        last[v.buf] = std::max(last[v.buf], hi[i]);
+    };
+    for (int i = 0; i < nops; ++i) {
+        const Op& o = c.ops[i];
+        touch(o.in, i); touch(o.out, i);
+        if (o.has_res) touch(o.res, i);
+        if (o.conv2 >= 0) touch(o.out2, i);
+    }
+    for (int k = 0; k < 3; ++k) last[c.heads[k].buf] = nops;          // the raw heads outlive the forward
+}
+
 void layout(y4_ctx& c) {
     // ---- activations
     size_t off = 0;
     c.zero_off = off; off += ZERO_PAGE_BYTES;
     const size_t nb = (size_t)c.cfg.max_batch;
-    for (auto& b : c.bufs) {
-        b.bytes = nb * b.side * b.side * b.channels * (b.f32 ? 4 : c.es);
-        b.offset = off;
-        off = align256(off + b.bytes);
+    for (auto& b : c.bufs) b.bytes = nb * b.side * b.side * b.channels * (b.f32 ? 4 : c.es);
+    if (!c.alias_bufs) {
+        for (auto& b : c.bufs) {
+            b.offset = off;
+            off = align256(off + b.bytes);
+        }
+    } else {
+        // greedy interval colouring by size: the largest buffer first, each at the lowest offset where it does not overlap (in
+        // memory) any already placed buffer whose lifetime intersects its own
+        std::vector<int> first, last, order(c.bufs.size());
+        buffer_lifetimes(c, first, last);
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return c.bufs[a].bytes != c.bufs[b].bytes ? c.bufs[a].bytes > c.bufs[b].bytes : a < b; });
+        const size_t base = align256(off);
+        size_t top = base;
+        std::vector<int> placed;
+        for (int bi : order) {
+            Buffer& b = c.bufs[bi];
+            size_t cand = base;
+            for (bool moved = true; moved;) {
+                moved = false;
+                for (int pj : placed) {
+                    const Buffer& o = c.bufs[pj];
+                    const bool live_together = !(last[bi] < first[pj] || last[pj] < first[bi]);
+                    if (live_together && cand < o.offset + align256(o.bytes) && o.offset < cand + align256(b.bytes)) {
+                        cand = o.offset + align256(o.bytes);
+                        moved = true;
+                    }
+                }
+            }
+            b.offset = cand;
+            placed.push_back(bi);
+            top = std::max(top, cand + align256(b.bytes));
+        }
+        off = top;
     }
     c.dbox_off = off; off = align256(off + nb * c.nbox * 16);
     c.cand_cap = (uint32_t)c.nbox * (uint32_t)c.cfg.num_classes;         // worst case: exact for any input
@@ -723,6 +793,15 @@ int y4_model_info(y4_handle h, int64_t* flops_per_image, int32_t* num_boxes, int
     return Y4_OK;
 }
 
+int y4_set_workspace_aliasing(y4_handle h, int on) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(!h->act, Y4_ESTATE, "y4_set_workspace_aliasing: the workspace is already bound (call it before y4_workspace_bytes / y4_bind_workspace)");
+    Y4_REQUIRE(!(on && h->sub_images > 0), Y4_ESTATE, "y4_set_workspace_aliasing: not together with sub-batching");
+    h->alias_bufs = on != 0;
+    layout(*h);
+    return Y4_OK;
+}
+
 int y4_workspace_bytes(y4_handle h, size_t* act_bytes, size_t* wts_bytes) {
     if (int r = check_handle(h)) return r;
     if (act_bytes) *act_bytes = h->act_bytes;
@@ -847,6 +926,7 @@ int y4_set_heads(y4_handle h, int n, const float* in_s, const float* in_m, const
 
 int y4_get_conv_output(y4_handle h, int conv_idx, int n, float* out, size_t out_floats, void* stream) {
     if (int r = check_ready(h, n)) return r;
+    Y4_REQUIRE(!h->alias_bufs, Y4_ESTATE, "intermediate tensors are not retained with workspace aliasing on");
     for (const Op& op : h->ops) {
         if (op.kind == OP_SPP || (op.conv != conv_idx && op.conv2 != conv_idx)) continue;
         Y4_REQUIRE(!(h->fuse_stem && conv_idx == 0), Y4_ESTATE, "conv 0 is not materialised while stem fusion is on");
@@ -1181,6 +1261,8 @@ int y4_set_tiles(y4_handle h, const int32_t* tiles, int count) {
 int y4_set_subbatch(y4_handle h, int images, int last_conv) {
     if (int r = check_handle(h)) return r;
     Y4_REQUIRE(h->t_max_steps == 0, Y4_ESTATE, "y4_set_subbatch: a timing session is open");
+    Y4_REQUIRE(images <= 0 || !h->alias_bufs, Y4_ESTATE, "y4_set_subbatch: not together with workspace aliasing (a sub-batch's "
+               "early tensors would share memory with another sub-batch's later ones)");
     if (images <= 0) { h->sub_images = 0; h->sub_last_op = -1; return Y4_OK; }
     int last_op = -1;
     for (int i = 0; i < (int)h->ops.size(); ++i)

@@ -35,7 +35,7 @@ def _cfg_struct(config, num_classes, max_batch, dtype):
 
 
 class Engine:
-    def __init__(self, num_classes, config=None, max_batch=32, dtype="f32", device=None):
+    def __init__(self, num_classes, config=None, max_batch=32, dtype="f32", device=None, alias_workspace=False):
         import torch
         self.torch = torch
         self.lib = ext.load()
@@ -55,6 +55,11 @@ class Engine:
         ext.check(self.lib.y4_model_info(self.handle, C.byref(flops), C.byref(nbox), C.byref(hcs), C.byref(wfl)))
         self.flops_per_image, self.num_boxes = flops.value, nbox.value
         self.head_cstride, self.weight_floats = hcs.value, wfl.value
+        # alias_workspace: activation buffers with disjoint lifetimes share memory (y4_set_workspace_aliasing): ~4x less
+        # activation memory; conv_output() taps are then unavailable
+        self.alias_workspace = bool(alias_workspace)
+        if self.alias_workspace:
+            ext.check(self.lib.y4_set_workspace_aliasing(self.handle, 1))
         a, w = C.c_size_t(), C.c_size_t()
         ext.check(self.lib.y4_workspace_bytes(self.handle, C.byref(a), C.byref(w)))
         self.act_bytes, self.wts_bytes = a.value, w.value
@@ -78,6 +83,9 @@ class Engine:
         e.num_classes, e.max_batch, e.cfg, e.dtype, e.img_size = self.num_classes, self.max_batch, self.cfg, self.dtype, self.img_size
         e.handle = C.c_void_p()
         ext.check(self.lib.y4_create(C.byref(e.cfg), C.byref(e.handle)))
+        e.alias_workspace = getattr(self, "alias_workspace", False)
+        if e.alias_workspace:
+            ext.check(self.lib.y4_set_workspace_aliasing(e.handle, 1))
         e.flops_per_image, e.num_boxes = self.flops_per_image, self.num_boxes
         e.head_cstride, e.weight_floats = self.head_cstride, self.weight_floats
         e.act_bytes, e.wts_bytes = self.act_bytes, self.wts_bytes

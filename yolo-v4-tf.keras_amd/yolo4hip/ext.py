@@ -72,6 +72,7 @@ SYMBOLS = {
     "y4_predict": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "y4_predict_u8": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "y4_profile": (_I, [_VP, _VP, _I, _VP, _VP, _I, C.POINTER(_I), _VP]),
+    "y4_set_workspace_aliasing": (_I, [_VP, _I]),
     "y4_autotune": (_I, [_VP, _I, _I, _VP]),
     "y4_autotune_pair": (_I, [_VP, _VP, _I, _I, _VP, _VP, _I]),
     "y4_get_tiles": (_I, [_VP, C.POINTER(C.c_int32), _I]),
