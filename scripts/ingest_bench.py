@@ -11,7 +11,7 @@ from yolo4hip.plan import build_plan
 
 size, ncls, n = 608, 80, 32
 plan = build_plan(size, ncls)
-eng = Engine(ncls, make_config(size), max_batch=n, dtype="bf16")
+eng = Engine(ncls, make_config(size), max_batch=n, dtype="bf16", alias_workspace=True)
 eng.load_weight_blob(W.flatten(W.synth_weights(plan, 0)))
 eng.set_stem_fusion(True)
 eng.set_chain_fusion(True)

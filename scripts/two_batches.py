@@ -14,7 +14,7 @@ from yolo4hip.plan import build_plan
 S = int(sys.argv[1]); mode = sys.argv[2] if len(sys.argv) > 2 else "solo"; B = 32; steps = 40
 passes = int(sys.argv[3]) if len(sys.argv) > 3 else 15      # pair mode: which decisions use the two-stream objective (bits 0..3)
 plan = build_plan(608, 80)
-eng = Engine(80, make_config(608), max_batch=B, dtype="bf16")
+eng = Engine(80, make_config(608), max_batch=B, dtype="bf16", alias_workspace=True)
 eng.load_weight_blob(W.flatten(W.synth_weights(plan, 0)))
 eng.set_stem_fusion(True); eng.set_chain_fusion(True); eng.set_stage_fusion(True); eng.set_res_fusion(True)
 imgs = [torch.from_numpy(W.synth_images(B, 608, 0, first_index=i * B)).cuda() for i in range(S)]
