@@ -156,6 +156,9 @@ def parse_args(argv):
                          "measured -1 %% and is 12 %% slower one stream at a time).  0 = plain y4_autotune")
     ap.add_argument("--save-tiles", default=None, help="write the autotuned per-layer tile ids to this JSON file")
     ap.add_argument("--load-tiles", default=None, help="use tile ids from this JSON file instead of autotuning")
+    ap.add_argument("--retune", action="store_true",
+                    help="autotune on this box even when a tuned schedule ships with the package for this shape "
+                         "(yolo4hip/schedules/: the headline shape's is the tile set profiles/r03 was profiled with)")
     ap.add_argument("--subbatch", type=int, default=0, help="images per sub-batch for the early layers (0 = whole batch)")
     ap.add_argument("--sub-last-conv", type=int, default=16)
     ap.add_argument("--no-stem-fusion", action="store_true", help="run convs 0 and 1 as two kernels (c0 through HBM)")
@@ -269,16 +272,29 @@ def main():
         eng.set_res_fusion(True)                   # residual blocks of the 64/128-channel stages as one kernel each
         res_mask = eng.res_fusion_mask()
     tune_pair = False
+    # the schedule: an explicit file, else the tuned one that ships for this shape (all fusions on, none of the debugging
+    # switches), else a one-off autotune on this box.  Every schedule gives the same bits; `schedule` in the line says which
+    schedule_src = "built-in heuristic (--no-autotune)"
+    saved = None
     if args.load_tiles:
         saved = json.load(open(args.load_tiles))
+        schedule_src = f"file {args.load_tiles}"
+    elif not args.retune and not args.no_autotune and args.subbatch == 0 and args.dtype != "f32" and fused_stem and chained \
+            and not args.no_stage_fusion and not args.no_res_fusion:
+        saved = eng.shipped_schedule()
+        if saved is not None and (int(saved.get("in_flight", args.in_flight)) != args.in_flight or len(saved.get("tiles", [])) != 110):
+            saved = None
+        if saved is not None:
+            schedule_src = "shipped with the package: yolo4hip/schedules/" + os.path.basename(saved["path"])
+            args.load_tiles = saved["path"]
+    if saved is not None:
         tiles = saved["tiles"]
-        eng.set_tiles(tiles)
-        if staged and "stage_fusion" in saved:
-            staged = bool(eng.set_stage_fusion(saved["stage_fusion"]))
-        if res_mask and "res_fusion_mask" in saved:
-            eng.set_res_fusion_mask(saved["res_fusion_mask"])
-            res_mask = eng.res_fusion_mask()
+        eng.apply_schedule(saved)
+        staged = bool(eng.stage_fusion_active()) if staged else False
+        res_mask = eng.res_fusion_mask() if res_mask else 0
     elif not args.no_autotune:
+        schedule_src = "autotuned in this process (y4_autotune_pair)" if args.in_flight > 1 and args.pair_passes > 0 else \
+            "autotuned in this process (y4_autotune)"
         eng.predict_device(imgs, outs)                        # real activations in the workspace
         tune_pair = args.in_flight > 1 and args.pair_passes > 0     # some decisions judged with D batches in flight
         if not tune_pair:
@@ -394,7 +410,7 @@ def main():
             "blocks_ms_per_step": [round(b / args.steps * 1e3, 4) for b in blocks],
             "timing": f"median of {args.blocks} blocks of {args.steps} steps, each barrier+synchronize bracketed, max over ranks; "
                       f"{depth} batch(es) in flight per GPU (step i on HIP stream / workspace i % {depth}, shared weights)",
-            "in_flight": depth,
+            "in_flight": depth, "schedule": schedule_src,
             "activation_workspace_bytes": int(eng.act_bytes), "workspace_aliasing": bool(args.alias_workspace),
             "single_stream_ms_per_step": round(single_ms, 4),
             "single_stream_value": round(args.batch * world / (single_ms * 1e-3), 2) if world == 1 else None,

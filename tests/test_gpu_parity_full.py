@@ -216,3 +216,31 @@ def test_bn_fold_with_real_statistics(dtype):
     wrong = OF.yolo_model_forward(imgs, flipped, ncls)
     assert max(float(np.abs(a - b).max()) for a, b in zip(heads, wrong)) > 0.5, "test has no power against a mean sign slip"
     eng.close()
+
+
+def test_shipped_schedule_keeps_the_bits_at_the_headline_shape():
+    """608x608 / 80 classes / batch 32 / bf16 with the schedule that ships for this shape (tuned tiles, stage kernel,
+    residual-block kernels: what the default bench.py and the Yolov4 facade run) against the built-in heuristic with every
+    fusion off: heads and detections bit-identical, on the liveness-aliased workspace."""
+    import torch
+    from yolo4hip import weights as W
+    from yolo4hip.config import make_config
+    from yolo4hip.engine import Engine
+    from yolo4hip.plan import build_plan
+    size, ncls, n = 608, 80, 32
+    eng = Engine(ncls, make_config(size), max_batch=n, dtype="bf16", alias_workspace=True)
+    sched = eng.shipped_schedule()
+    assert sched is not None and len(sched["tiles"]) == 110
+    eng.load_weight_blob(W.flatten(W.synth_weights(build_plan(size, ncls), 0)))
+    imgs = torch.from_numpy(W.synth_images(n, size, seed=11)).to(eng.device)
+    plain = [o.cpu().numpy() for o in eng.predict_device(imgs)]
+    plain_heads = [h.cpu().numpy() for h in eng.heads_device(n)]
+    eng.set_stem_fusion(True); eng.set_chain_fusion(True); eng.set_stage_fusion(True); eng.set_res_fusion(True)
+    eng.apply_schedule(sched)
+    assert eng.stage_fusion_active() == bool(sched["stage_fusion"]) and eng.res_fusion_mask() == sched["res_fusion_mask"]
+    got = [o.cpu().numpy() for o in eng.predict_device(imgs)]
+    got_heads = [h.cpu().numpy() for h in eng.heads_device(n)]
+    for a, b in zip(got + got_heads, plain + plain_heads):
+        assert np.array_equal(a, b)
+    assert int(got[3].sum()) > 0            # there are detections to compare
+    eng.close()

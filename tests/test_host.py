@@ -163,3 +163,16 @@ def test_resize_bilinear_against_independent_bilinear(src_hw, dst_wh):
     # measured: max |diff| vs the unrounded float result 0.50-0.81 LSB; 87-99.7 % of the pixels equal the ROUNDED float
     # result, the rest are 1 LSB off (11-bit coefficients and the two truncating shifts of the fixed-point scheme)
     assert exact > 0.85, exact
+
+
+def test_shipped_schedule_is_the_profiled_tile_set():
+    """The schedule that ships for the headline shape (yolo4hip/schedules/608_80_32_bf16.json, what the default bench.py
+    loads) is byte for byte the tile set the committed PMC passes were taken with (profiles/r03/tiles.json) -- that is what
+    lets bench.py quote profiles/r03/hbm_traffic.json as `roofline.traffic` -- and names one tile per conv."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shipped = json.load(open(os.path.join(root, "yolo-v4-tf.keras_amd", "yolo4hip", "schedules", "608_80_32_bf16.json")))
+    profiled = json.load(open(os.path.join(root, "profiles", "r03", "tiles.json")))
+    assert shipped == profiled
+    assert (shipped["size"], shipped["classes"], shipped["batch"], shipped["dtype"]) == (608, 80, 32, "bf16")
+    assert len(shipped["tiles"]) == 110 and shipped["in_flight"] == 2

@@ -67,6 +67,11 @@ class Yolov4(object):
             if self.img_size[0] <= 640:
                 self.engine.set_stem_fusion(True)
             self.engine.set_chain_fusion(True)
+            sched = self.engine.shipped_schedule()       # tuned tiles / stage kernel / residual-block kernels, if this shape has one
+            if sched is not None:
+                self.engine.set_stage_fusion(True)
+                self.engine.set_res_fusion(True)
+                self.engine.apply_schedule(sched)
         self.yolo_model = _KerasLikeModel(self.engine.forward_heads, 'yolo_model')
         print(f"nms iou: {self.config['iou_threshold']} score: {self.config['score_threshold']}")
         self.inference_model = _KerasLikeModel(self.engine.predict, 'inference_model')

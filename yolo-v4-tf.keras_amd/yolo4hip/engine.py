@@ -490,6 +490,33 @@ class Engine:
         ext.check(self.lib.y4_get_tiles(self.handle, tiles, 110))
         return list(tiles)
 
+    # ---------------------------------------------------------------- shipped schedules
+    def shipped_schedule(self):
+        """The tuned schedule that ships with the package for this (image side, classes, batch, dtype), or None: the
+        per-launch tile ids, the stage-kernel switch and the residual-block mask one `autotune` run chose on an MI355X
+        (`yolo4hip/schedules/<side>_<classes>_<batch>_<dtype>.json`; the headline shape's file IS `profiles/r03/tiles.json`,
+        the set the committed PMC passes profiled).  Every choice is bit-identical to every other, so a shipped schedule
+        changes speed only."""
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "schedules",
+                            f"{self.img_size}_{self.num_classes}_{self.max_batch}_{self.dtype}.json")
+        try:
+            saved = json.load(open(path))
+        except (OSError, ValueError):
+            return None
+        saved["path"] = path
+        return saved
+
+    def apply_schedule(self, saved):
+        """Tiles / stage kernel / residual-block mask from a schedule dict (`shipped_schedule`, `bench.py --save-tiles`).  The
+        fusion switches themselves (stem, chains, stage, residual blocks) must already be on: a schedule only narrows them."""
+        self.set_tiles(saved["tiles"])
+        if self.dtype != "f32" and "stage_fusion" in saved and self.stage_fusion_active():
+            self.set_stage_fusion(bool(saved["stage_fusion"]))
+        if self.dtype != "f32" and "res_fusion_mask" in saved and self.res_fusion_mask():
+            self.set_res_fusion_mask(int(saved["res_fusion_mask"]))
+
     def set_tiles(self, tiles):
         arr = (C.c_int32 * len(tiles))(*[int(t) for t in tiles])
         ext.check(self.lib.y4_set_tiles(self.handle, arr, len(tiles)))
