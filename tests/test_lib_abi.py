@@ -68,3 +68,32 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("ext.load() must raise when the shared library is missing")
+
+
+def test_workspace_aliasing_layout_host_only():
+    """y4_set_workspace_aliasing is pure host work (liveness over the plan, interval placement): without a GPU it must
+    shrink the activation workspace to well under half for every BASELINE shape, leave the weight workspace alone, be
+    reversible before the workspace is bound, and refuse sub-batching while on."""
+    from yolo4hip import ext
+    from yolo4hip.config import make_config
+    from yolo4hip.engine import _cfg_struct
+    lib = ext.load()
+    for size, ncls, nb, dt in ((608, 80, 32, "bf16"), (416, 3, 64, "f16"), (608, 80, 1, "f32"), (416, 80, 2, "f32")):
+        cfg = _cfg_struct(make_config(size), ncls, nb, dt)
+        h = C.c_void_p()
+        ext.check(lib.y4_create(C.byref(cfg), C.byref(h)))
+        sizes = []
+        for on in (0, 1, 0, 1):
+            ext.check(lib.y4_set_workspace_aliasing(h, on))
+            a, w = C.c_size_t(), C.c_size_t()
+            ext.check(lib.y4_workspace_bytes(h, C.byref(a), C.byref(w)))
+            sizes.append((a.value, w.value))
+        assert sizes[0] == sizes[2] and sizes[1] == sizes[3]
+        assert sizes[1][1] == sizes[0][1]                       # weights untouched
+        assert sizes[1][0] < 0.45 * sizes[0][0], (size, nb, dt, sizes)
+        assert lib.y4_set_subbatch(h, 1, 16) == -1 and b"aliasing" in lib.y4_last_error()
+        ext.check(lib.y4_set_workspace_aliasing(h, 0))
+        if nb > 1:
+            ext.check(lib.y4_set_subbatch(h, 1, 16))
+            assert lib.y4_set_workspace_aliasing(h, 1) == -1    # ... and the other way round
+        lib.y4_destroy(h)
