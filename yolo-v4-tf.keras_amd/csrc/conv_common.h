@@ -52,6 +52,7 @@ struct ConvK {
     char* fin2;                    // the tail is a fused CSP pair: its rows >= tail_split go to this view
     int fin2_cstride, fin2_coff, tail_split;
     int tail_k, tail_panel0;       // the tail reads tail_k input channels starting at LDS panel tail_panel0 (64 channels each)
+    int touch;                     // != 0: the workgroups of an XCD touch this channel tile's weights into their L2 at start (weight_touch)
 };
 
 template <int CPR> __device__ __forceinline__ int swz(int row) {
@@ -102,6 +103,25 @@ template <> struct Mma32<Y4_F32> {     // (never instantiated for real: the fp32
 // for the host pass too, which silently drops the kernel's host stub.
 __device__ __forceinline__ void buffer_load16_lds(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, int soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
+}
+// one dword per lane, same addressing: used to TOUCH a cache line (the data lands in an LDS scratch nobody reads)
+__device__ __forceinline__ void buffer_load4_lds(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 4, voffset, soffset, 0, 0);
+}
+// Weight touch.  In a step a layer's weights are in no L2 when its kernel starts, and the workgroups of an XCD walk them in
+// lock-step: every K-tile's weight rows are a cold miss for all of them at once, K-tile after K-tile, each miss longer than
+// the one K-tile the staging ring looks ahead (measured, scripts/touch_probe.sh: a 3x3 256->256 @38^2 takes 60 us in a step
+// against 50 in a hot loop, its 1x1 neighbours 19 against 13).  So the workgroups that run together on an XCD (blockIdx.x >> 3
+// counts them; at most 32 CUs) share out the `bytes` of the block they are all about to stream and touch it once, one
+// dword per 128-byte line, before their first stage: about one load instruction per wave, every miss in flight together,
+// and the ring's loads then hit L2.  The dwords land in an LDS scratch of 256 bytes per wave that nobody reads -- callers
+// pass the wave's own first staging piece, which its own first stage load (issued later; a wave's loads retire in order)
+// overwrites.  No arithmetic is involved: results cannot change.
+__device__ __forceinline__ void weight_touch(__amdgpu_buffer_rsrc_t rs, char* wave_scratch, int byte0, int bytes, int wave, int nwaves, int lane) {
+    const int me = ((int)blockIdx.x >> 3) & 31;
+    const int lines = bytes >> 7;
+    for (int i = (me * nwaves + wave) * 64 + lane; i < lines; i += 32 * nwaves * 64)
+        buffer_load4_lds(rs, wave_scratch, byte0 + i * 128, 0);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);

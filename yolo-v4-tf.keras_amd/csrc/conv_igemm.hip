@@ -22,6 +22,12 @@ int conv_p8_launch(int dtype, int bm, int nst, const ConvK& k, hipStream_t s) {
 
 int conv_tile_count() { return kNumTiles; }
 
+// the weight touch of conv_common.h is on unless Y4_NO_WEIGHT_TOUCH=1 (A/B measurements only: results are the same)
+bool weight_touch_enabled() {
+    static const bool on = [] { const char* e = getenv("Y4_NO_WEIGHT_TOUCH"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
 static bool tile_ok(const TileCfg& tc, int dtype, int cin, int cout_pad) {
     const int bk = tc.bkb / elem_size(dtype);
     return cin % bk == 0 && cout_pad % tc.bn == 0;
@@ -115,6 +121,7 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
     Y4_REQUIRE(k.ntail == 0 || chain_tile(tile), Y4_EINVAL, "conv2d: tile id %d cannot head this chain", tile);
     Y4_REQUIRE(!pair || (pair_tile(tile) && kTiles[tile - 1].bn == d->cout), Y4_EINVAL, "conv2d: tile id %d cannot head this LDS pair", tile);
     Y4_REQUIRE(tile >= 1 && tile <= kNumTiles, Y4_EINVAL, "conv2d: tile id %d out of range", tile);
+    k.touch = weight_touch_enabled() ? 1 : 0;
     const TileCfg& tc = kTiles[tile - 1];
     Y4_REQUIRE(tile_ok(tc, d->dtype, d->cin, cout_pad), Y4_EINVAL,
                "conv2d: tile %d (bk bytes %d, bn %d) does not fit cin %d / cout_pad %d", tile, tc.bkb, tc.bn,

@@ -188,6 +188,13 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         }
     };
 
+    // ---- weight touch (conv_common.h): this channel tile's weight block, BN rows x K, is contiguous
+    if (p.touch != 0) {
+        weight_touch(rs_wt, smem + wave_lds, n0 * p.K * ES, BN * p.K * ES, wave, NT / 64, lane);
+        if constexpr (PAIR)                    // ... and the tail conv's, needed only after the whole K loop
+            weight_touch(make_rsrc(p.tail[0].w, p.tail_w_bytes), smem + wave_lds, 0, (int)p.tail_w_bytes, wave, NT / 64, lane);
+    }
+
     // ---- fragment read addresses (row & swizzle depend on the lane only)
     const int frow = lane & 15, fg = lane >> 4;
     int xo[KSTEPS];

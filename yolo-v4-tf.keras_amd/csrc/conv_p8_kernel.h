@@ -171,6 +171,7 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(p.wt, p.wt_bytes);
     const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
+    if (p.touch != 0) weight_touch(rs_wt, smem + wave_lds, n0 * p.K * ES, 256 * p.K * ES, wave, 8, lane);     // conv_common.h
     const int nk = p.K / BK;
     // staging cursor: the K-tile whose regions are being issued (tap, byte offset of c0, byte offset of k in the weights)
     int tap = 0, ky = 0, kx = 0, c0b = 0, ktb = 0, lk = 0;

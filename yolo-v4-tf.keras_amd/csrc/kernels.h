@@ -35,6 +35,7 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
                   const ConvPairDesc* pair = nullptr);
 int pack_tail_weights(int dtype, int cout, int cin, const float* oihw, void* packed, hipStream_t stream);
 int conv_tile_count();
+bool weight_touch_enabled();          // conv_common.h: weight_touch (off with Y4_NO_WEIGHT_TOUCH=1, for A/B runs)
 int conv_pick_tile(int dtype, int M, int cin, int cout);
 int pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw, void* packed, hipStream_t stream);
 

@@ -64,6 +64,7 @@ struct ResBlockK {
     unsigned in_bytes;
     int N, S;
     int tiles_x, tiles_per_img, ntiles;
+    int touch;                   // weight touch (conv_common.h) of the block's blob at kernel start
 };
 
 template <int DT, int C>
@@ -87,6 +88,9 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
 
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.blob, G::BLOB_BYTES);
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
+    // the blob (affine tables + both convs' weight streams: every tile streams all of it) -> this XCD's L2, shared out over the
+    // workgroups (conv_common.h: weight_touch); the dwords land in the wave's piece of ring slot 0, which its stage_w(0) overwrites
+    if (p.touch != 0) weight_touch(rb, ring + __builtin_amdgcn_readfirstlane(wave * 1024), 0, G::BLOB_BYTES, wave, RB_WAVES, lane);
     // affine -> LDS once per workgroup
     for (int u = wave; u < G::AFF_PAD / 1024; u += RB_WAVES)
         buffer_load16_lds(rb, smem + __builtin_amdgcn_readfirstlane(u * 1024), u * 1024 + lane * 16, 0);
@@ -336,6 +340,7 @@ int resblock_launch(int dtype, int c, const void* in, int n, int side, int in_cs
     k.in_cstride = in_cstride; k.in_coff = in_coff; k.out_cstride = out_cstride; k.out_coff = out_coff;
     k.in_bytes = (unsigned)in_bytes;
     k.N = n; k.S = side;
+    k.touch = weight_touch_enabled() ? 1 : 0;
     k.tiles_x = (side + RB_T - 1) / RB_T; k.tiles_per_img = k.tiles_x * k.tiles_x; k.ntiles = n * k.tiles_per_img;
     if (c == 128) return dtype == Y4_BF16 ? resblock_dispatch<Y4_BF16, 128>(k, stream) : resblock_dispatch<Y4_F16, 128>(k, stream);
     return dtype == Y4_BF16 ? resblock_dispatch<Y4_BF16, 64>(k, stream) : resblock_dispatch<Y4_F16, 64>(k, stream);
