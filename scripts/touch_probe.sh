@@ -1,6 +1,5 @@
 # A/B of the weight touch (conv_common.h: weight_touch; Y4_NO_WEIGHT_TOUCH=1 turns it off), shipped schedule, alternating
 mkdir -p gpurun_out/touch
-python -m pytest tests/test_gpu_conv.py tests/test_gpu_forward.py -x -q 2>&1 | tail -2
 for r in 1 2 3; do for t in 1 0; do
   Y4_NO_WEIGHT_TOUCH=$t python bench.py --no-cpu-baseline --in-flight 1 > gpurun_out/touch/s1_$t.json 2>/dev/null
   Y4_NO_WEIGHT_TOUCH=$t python bench.py --no-cpu-baseline > gpurun_out/touch/s2_$t.json 2>/dev/null
@@ -11,11 +10,3 @@ e=json.loads(open(f'gpurun_out/touch/s2_{sys.argv[1]}.json').read().strip().spli
 print('no_touch', sys.argv[1], '| one stream', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernel_ms_per_step'], '| two in flight', e['value'], e['ms_per_step'], e['single_stream_value'], e['outputs_sha256'][:12])
 PY
 done; done
-for t in 1 0; do Y4_NO_WEIGHT_TOUCH=$t python bench.py --no-cpu-baseline --size 416 --classes 3 --batch 64 --dtype f16 > gpurun_out/touch/c5_$t.json 2>/dev/null; Y4_NO_WEIGHT_TOUCH=$t python bench.py --no-cpu-baseline --batch 1 --dtype f32 --steps 50 > gpurun_out/touch/c2_$t.json 2>/dev/null
-python - $t <<'PY'
-import json,sys
-for c in ('c5','c2'):
-    d=json.loads(open(f'gpurun_out/touch/{c}_{sys.argv[1]}.json').read().strip().splitlines()[-1])
-    print(c,'no_touch', sys.argv[1], d['value'], d['ms_per_step'], d['single_stream_value'], d['roofline']['frac'])
-PY
-done
