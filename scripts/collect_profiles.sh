@@ -18,7 +18,10 @@ cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r3set; rm -rf $O; mkdir -p $O/pmc
 SMI="rocm-smi --showclocks --showpower --showtemp --showperflevel --showmaxpower"
 $SMI > $O/smi_idle.txt 2>&1
-python bench.py --retune --save-tiles $O/tiles.json > $O/bench.json 2> $O/bench.err      # tuned on THIS box; afterwards: cp tiles.json to yolo4hip/schedules/608_80_32_bf16.json
+# the schedule of the whole set: $Y4_COLLECT_TILES (a schedule file, e.g. scripts/instep_select.py's) if given, else a fresh autotune on THIS box;
+# afterwards tiles.json is what ships as yolo4hip/schedules/608_80_32_bf16.json
+if [ -n "$Y4_COLLECT_TILES" ]; then cp "$Y4_COLLECT_TILES" $O/tiles.json; python bench.py --load-tiles $O/tiles.json > $O/bench.json 2> $O/bench.err
+else python bench.py --retune --save-tiles $O/tiles.json > $O/bench.json 2> $O/bench.err; fi
 # steady single-stream load for ~45 s; the sampler starts once the engine is up and the steps are running
 python bench.py --no-cpu-baseline --load-tiles $O/tiles.json --in-flight 1 --steps 1500 --blocks 5 > $O/bench_single_stream.json 2> $O/bench_single_stream.err &
 BPID=$!
