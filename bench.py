@@ -14,10 +14,18 @@ indices), as SURVEY.md section 8(d) defines the metric.  Timing: W untimed warm-
 blocks of EXACTLY K steps, each block bracketed by barrier + torch.cuda.synchronize() on both sides and reduced with MAX
 over ranks; `ms_per_step` / `value` are the MEDIAN block (one 0.13 s sample on a pool whose boxes differ by +-3 % was too
 noisy), every block is listed under `blocks_ms_per_step`.
+By default `--in-flight 2`: step i runs on HIP stream / activation workspace i % 2 (two independent batches overlap on the
+GPU; every step of a block still completes inside the block's bracket); `--in-flight 1` = every step on one stream, and
+`single_stream_value` in the line is that rate measured in the same process.
+Schedule (tile per launch, fusion kernels on / off -- every choice gives the same bits): the tuned one that ships for the
+shape (yolo4hip/schedules/, the kernel mix profiles/r03 was profiled with) if there is one, else a one-off autotune on this
+box; `--retune` forces the autotune, `--load-tiles` a file; `schedule` in the line says which ran.
 `roofline` is for the dominant kernel family (the conv kernels: convs 2..109 with the stem fusion, else 1..109):
 algorithmic conv FLOPs of one step / its summed device time, measured with HIP events recorded on the launch stream
-inside the timed blocks (y4_timing_begin/end).  `cpu_baseline` times the oracle (a torch-CPU/NumPy restatement; the
-reference's tf.keras path cannot run here) on a bounded sample on rank 0 at N=1.
+(y4_timing_begin/end) -- inside the timed blocks with one stream, in a single-stream pass right after them with two
+(`roofline.measured_in`); `roofline.traffic` quotes the committed PMC passes when the schedule is the profiled one, else
+null with the reason.  `cpu_baseline` times the oracle (a torch-CPU/NumPy restatement; the reference's tf.keras path cannot
+run here) on a bounded sample on rank 0 at N=1.
 """
 import argparse
 import json
