@@ -100,3 +100,69 @@ def test_custom_thresholds_like_predict_nonms():
     _compare(eng, cfg, heads, size, ncls, iou=0.9, score=0.5)
     _compare(eng, cfg, heads, size, ncls, iou=0.0, score=0.05)
     eng.close()
+
+
+def _heads_with(size, ncls, n, boxes):
+    """Logits that are hugely negative everywhere except the listed (image, scale, gy, gx, anchor, class, obj_logit, cls_logit,
+    txywh) cells: exactly those boxes are candidates."""
+    nf = 5 + ncls
+    heads = [np.full((n, size // s, size // s, 3, nf), -20.0, np.float32) for s in (8, 16, 32)]
+    for h in heads:
+        h[..., :4] = 0.0
+    for (b, sc, gy, gx, a, c, lo, lc, t) in boxes:
+        heads[sc][b, gy, gx, a, :4] = t
+        heads[sc][b, gy, gx, a, 4] = lo
+        heads[sc][b, gy, gx, a, 5 + c] = lc
+    return [h.reshape(n, h.shape[1], h.shape[2], 3 * nf) for h in heads]
+
+
+def test_empty_single_and_mixed_images():
+    """Edge cases of tf.image.combined_non_max_suppression's padded outputs: an image with no candidate at all (valid 0, all
+    zeros), one with exactly one, and both in ONE batch next to a crowded image -- rows are independent."""
+    size, ncls, n = 160, 5, 3
+    cfg, eng = _engine(size, ncls, n)
+    rng = np.random.default_rng(5)
+    crowded = _random_heads(rng, 1, size, ncls, 1.0, 0.0)
+    one = _heads_with(size, ncls, 1, [(0, 1, 3, 4, 2, 3, 6.0, 6.0, (0.2, -0.1, 0.3, 0.1))])
+    none = _heads_with(size, ncls, 1, [])
+    heads = [np.concatenate([none[s], one[s], crowded[s]], axis=0) for s in range(3)]
+    got, ref = _compare(eng, cfg, heads, size, ncls)
+    assert list(got[3][:2]) == [0, 1] and got[3][2] > 1
+    assert np.all(got[0][0] == 0) and np.all(got[1][0] == 0) and np.all(got[2][0] == 0) and np.all(got[4][0] == -1)
+    assert got[2][1, 0] == 3 and np.all(got[1][1, 1:] == 0)
+    eng.close()
+
+
+def test_identical_boxes_of_different_classes_all_survive():
+    """Class-aware suppression: the SAME box scored for every class is kept once per class (IoU 1 only suppresses within a
+    class), in descending score order; two identical boxes of ONE class collapse to the better one."""
+    size, ncls, n = 96, 4, 1
+    cfg, eng = _engine(size, ncls, n)
+    t = (0.0, 0.0, 0.2, 0.2)
+    boxes = [(0, 0, 5, 5, 1, c, 8.0, 2.0 + c, t) for c in range(ncls)]
+    heads = _heads_with(size, ncls, n, boxes)
+    # all four class logits sit in the same cell/anchor: one box, four classes
+    got, ref = _compare(eng, cfg, heads, size, ncls)
+    assert got[3][0] == ncls and list(got[2][0, :ncls]) == [3, 2, 1, 0]
+    assert np.all(got[0][0, :ncls] == got[0][0, 0])
+    # the neighbouring anchor slot with the same decoded box is a different box index of the same class 0 -> suppressed
+    eng.close()
+
+
+def test_more_than_the_cap_of_disjoint_boxes():
+    """> max_total (100) non-overlapping boxes of one class above the threshold: exactly the 100 best survive, in score order,
+    ties by box index (the oracle's stable order)."""
+    size, ncls, n = 416, 2, 1
+    cfg, eng = _engine(size, ncls, n)
+    boxes = []
+    g = size // 8
+    k = 0
+    for gy in range(0, g, 4):
+        for gx in range(0, g, 4):
+            boxes.append((0, 0, gy, gx, 0, 1, 6.0, 3.0 + 0.01 * (k % 37), (0.0, 0.0, -0.5, -0.5)))
+            k += 1
+    assert len(boxes) > 150
+    heads = _heads_with(size, ncls, n, boxes)
+    got, ref = _compare(eng, cfg, heads, size, ncls)
+    assert got[3][0] == 100 and np.all(np.diff(got[1][0]) <= 0) and np.all(got[2][0] == 1)
+    eng.close()
