@@ -34,12 +34,15 @@ __device__ __forceinline__ void chain_load_affine(const float* scale, const floa
 // Shape of a chain (compile time, so that each gets its own register allocation):
 //   CFG 1: head 64 ch -> tail 64          CFG 2: head 64 -> 64 -> (64 | partner 64) -> 64
 //   CFG 3: head 64 -> 64 -> (64 | partner 64) -> 128
+//   CFG 4: head 64 -> (64 | partner 64) -> 128      (no 64 -> 64 tail: the head IS the conv before the concat; ConvK::tail[1]
+//          describes the conv over the concat, tail[0] is unused) -- the post conv of a CSP stage whose last residual block
+//          runs in resblock_kernel, chained to the conv over the concat (custom_layers.py:66-69)
 template <int CFG> struct ChainShape {
     static constexpr int HEAD_NREP = 4;
-    static constexpr int T0_K = 64;
-    static constexpr int T0_COUT = 64;
-    static constexpr int T1_K = (CFG == 2 || CFG == 3) ? 128 : 0;
-    static constexpr int T1_COUT = CFG == 2 ? 64 : (CFG == 3 ? 128 : 0);
+    static constexpr int T0_K = CFG == 4 ? 0 : 64;
+    static constexpr int T0_COUT = CFG == 4 ? 0 : 64;
+    static constexpr int T1_K = (CFG == 2 || CFG == 3 || CFG == 4) ? 128 : 0;
+    static constexpr int T1_COUT = CFG == 2 ? 64 : ((CFG == 3 || CFG == 4) ? 128 : 0);
     static constexpr int T0_BYTES = T0_COUT * T0_K * 2, T1_BYTES = T1_COUT * T1_K * 2;
     static constexpr int LDS_BYTES = T0_BYTES + T1_BYTES;
 };
@@ -50,9 +53,11 @@ template <int CFG> struct ChainShape {
 template <int CFG, int NWAVES>
 __device__ __forceinline__ void chain_stage_weights(const ConvK& p, char* lds, int wave, int lane) {
     using S = ChainShape<CFG>;
-    const __amdgpu_buffer_rsrc_t r0 = make_rsrc(p.tail[0].w, S::T0_BYTES);
-    for (int u = wave; u < S::T0_BYTES / 1024; u += NWAVES)
-        buffer_load16_lds(r0, lds + __builtin_amdgcn_readfirstlane(u * 1024), u * 1024 + lane * 16, 0);
+    if constexpr (S::T0_BYTES != 0) {
+        const __amdgpu_buffer_rsrc_t r0 = make_rsrc(p.tail[0].w, S::T0_BYTES);
+        for (int u = wave; u < S::T0_BYTES / 1024; u += NWAVES)
+            buffer_load16_lds(r0, lds + __builtin_amdgcn_readfirstlane(u * 1024), u * 1024 + lane * 16, 0);
+    }
     if constexpr (S::T1_BYTES != 0) {
         const __amdgpu_buffer_rsrc_t r1 = make_rsrc(p.tail[1].w, S::T1_BYTES);
         for (int u = wave; u < S::T1_BYTES / 1024; u += NWAVES)
@@ -157,8 +162,23 @@ __device__ __forceinline__ void chain_epilogue(const ConvK& p, const char* lds_w
         for (int c = 0; c < HC; ++c) E::store_chunk(&X[i][c], v + c * 8);
         if (p.store_x && m < m_limit) chain_store<DT, 2>(p.out, m, p.out_cstride, p.out_coff, fg, &X[i][0]);
     }
+    if constexpr (S::T0_K == 0) {
+        // ---- CFG 4: the conv over Concatenate([the head's 64 channels, partner's 64]) straight away
+        constexpr int N1 = S::T1_COUT / 16;
+        f32x4 a1[MREP][N1];
+        chain_gemm<DT, MREP, N1, 4>(lds_w, lane, a1, [&](int i, int s) -> const u32x4& { return s < 2 ? X[i][s] : pf.x2[i][s - 2]; });
+        float sc1[N1 * 4], sh1[N1 * 4];
+        chain_load_affine<N1 / 2>(p.tail[1].scale, p.tail[1].shift, 0, fg, sc1, sh1);
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) {
+            u32x4 Z[N1 / 2];
+            chain_bn_act_pack<DT, N1>(a1[i], sc1, sh1, Z);
+            if (mrow + i * 16 < m_limit) chain_store<DT, N1 / 2>(p.fin, mrow + i * 16, p.fin_cstride, p.fin_coff, fg, Z);
+        }
+        return;
+    }
     // ---- tail 0: the head's 64 channels -> 64
-    constexpr int N0 = S::T0_COUT / 16, XOFF = 0;
+    constexpr int N0 = S::T0_COUT ? S::T0_COUT / 16 : 4, XOFF = 0;
     f32x4 a0[MREP][N0];
     chain_gemm<DT, MREP, N0, 2>(lds_w, lane, a0, [&](int i, int s) -> const u32x4& { return X[i][XOFF + s]; });
     float sc0[N0 * 4], sh0[N0 * 4];

@@ -107,7 +107,9 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
                    Y4_EINVAL, "conv2d: bad chain description");
         k.ntail = chain->ntail; k.store_x = chain->store_x;
         k.fin = (char*)chain->fin; k.fin_cstride = chain->fin_cstride; k.fin_coff = chain->fin_coff;
-        for (int t = 0; t < chain->ntail; ++t) {
+        Y4_REQUIRE(!chain->concat_only || (chain->ntail == 2 && chain->tail[1].cout == 128 && !chain->store_x), Y4_EINVAL,
+                   "conv2d: a head chained straight to the conv over the concat needs ntail = 2, 128 output channels, no own store");
+        for (int t = chain->concat_only ? 1 : 0; t < chain->ntail; ++t) {
             const auto& ct = chain->tail[t];
             Y4_REQUIRE(ct.w && ct.scale && ct.shift && (ct.cout == 64 || (ct.cout == 128 && t == chain->ntail - 1)) &&
                            ((t == 1) == (ct.src2 != nullptr)) && (!ct.src2 || (ct.src2_cstride % epc == 0 && ct.src2_coff % epc == 0)),

@@ -561,7 +561,7 @@ static int launch_fused(int tile, const ConvK& k, hipStream_t s) {
     }
     if (k.ntail > 0) {
         if constexpr (DT != Y4_F32) {
-            const int cfg = k.ntail == 1 ? 1 : (k.tail[1].cout == 64 ? 2 : 3);
+            const int cfg = k.ntail == 1 ? 1 : (k.tail[0].w == nullptr ? 4 : (k.tail[1].cout == 64 ? 2 : 3));
 #define Y4_CHAIN_CASE(CFG)                                                                   \
     case CFG:                                                                                \
         switch (tile) {                                                                      \
@@ -570,7 +570,7 @@ static int launch_fused(int tile, const ConvK& k, hipStream_t s) {
             case 15: return launch_cfg<DT, 128, 64, 4, 1, 64, 4, CFG>(k, s);                 \
         }                                                                                    \
         break;
-            switch (cfg) { Y4_CHAIN_CASE(1) Y4_CHAIN_CASE(2) Y4_CHAIN_CASE(3) }
+            switch (cfg) { Y4_CHAIN_CASE(1) Y4_CHAIN_CASE(2) Y4_CHAIN_CASE(3) Y4_CHAIN_CASE(4) }
 #undef Y4_CHAIN_CASE
         }
         set_error("conv2d: tile id %d cannot head a chain", tile);

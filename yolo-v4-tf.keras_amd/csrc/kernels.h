@@ -8,7 +8,8 @@ namespace y4 {
 // 1x1 convs chained onto a conv's register tile (conv_chain.h); d->out is then the head conv's own output view,
 // written only if store_x, and the last tail writes `fin`.  16-bit dtypes, head cout == 64, Mish everywhere.
 struct ConvChainDesc {
-    int ntail, store_x;
+    int ntail, store_x;            // (concat_only: ntail = 2 with tail[0] unused -- the head feeds the conv over the concat directly)
+    int concat_only;
     struct {
         const void* w;             // pack_tail_weights layout
         const float* scale;

@@ -67,6 +67,10 @@ struct Chain {
     bool lds_pair = false;  // the tail runs from the head's tile kept in LDS (128/256 channels), not from registers
     bool enabled = true;    // y4_autotune turns a run off when its separate kernels measure faster
     int tile = 0;           // the head's tile when it runs chained (0 = heuristic); Op::tile stays the unfused choice
+    // "Alternative" run (conv_chain.h CFG 4): the 64 -> 64 tail of run `alt_of` as a HEAD chained straight to that run's conv
+    // over the concat (tail[0] here).  In force only while run `alt_of` cannot exist because its own head executes inside
+    // a residual-block kernel.
+    int alt_of = -1;
 };
 
 // A residual block "1x1 conv -> 3x3 conv + Add(block input)" executed as one spatially tiled kernel (resblock.hip)
@@ -128,6 +132,16 @@ struct y4_ctx {
         for (const ResRun& r : resruns)
             if ((r.head == oi || r.tail == oi) && res_enabled[r.c == 128 ? 0 : 1]) { if (is_head) *is_head = r.head == oi; return &r; }
         return nullptr;
+    }
+    // does this run execute as one kernel under the current settings?  (force_chain: the tuner times an alternative run while
+    // the residual-block kernels are switched off)
+    int force_chain = -1;
+    bool chain_active(const Chain& ch) const {
+        if (!fuse_chains || !ch.enabled) return false;
+        const int ci = (int)(&ch - chains.data());
+        if (ch.alt_of >= 0) return ci == force_chain || res_of(chains[ch.alt_of].head, nullptr) != nullptr;
+        if (force_chain >= 0 && chains[force_chain].alt_of == ci) return false;
+        return res_of(ch.head, nullptr) == nullptr;
     }
     // images of the current call are uint8 frames at network size (y4_forward_u8 / y4_predict_u8): the stem divides by 255
     bool img_u8 = false;
@@ -355,6 +369,14 @@ void find_chains(y4_ctx& c) {
         c.layers[b.conv].has_tail = true;
         if (ch.tail[1] >= 0) c.layers[c.ops[ch.tail[1]].conv].has_tail = true;
         c.chains.push_back(ch);
+    }
+    // alternatives (CFG 4): [1x1 64 -> 64] -> [1x1 over the concat, 128 -> 128] of every three-conv run above
+    for (size_t ci = 0, nci = c.chains.size(); ci < nci; ++ci) {
+        const Chain& pc = c.chains[ci];
+        if (pc.lds_pair || pc.tail[1] < 0 || c.layers[c.ops[pc.tail[1]].conv].d.cout != 128) continue;
+        Chain alt{pc.tail[0], {pc.tail[1], -1}, false};
+        alt.alt_of = (int)ci;
+        c.chains.push_back(alt);
     }
     // LDS pairs: conv (128 or 256 output channels) -> 1x1 conv with the same channel count reading exactly that output
     // (the residual blocks of the 76^2 and 38^2 stages: 3x3 + Add -> the next block's 1x1, custom_layers.py:34-44)
@@ -620,7 +642,7 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
     const Chain* chain = nullptr;
     if (h->fuse_chains && allow_chain && op.kind == OP_CONV)
         for (const Chain& ch : h->chains) {
-            if (!ch.enabled || h->res_of(ch.head, nullptr)) continue;     // (a head inside a residual-block kernel: its tails run alone)
+            if (!h->chain_active(ch)) continue;     // (a head inside a residual-block kernel: its tails run alone or as the alternative run)
             if (&h->ops[ch.head] == &op) chain = &ch;
             else if (&h->ops[ch.tail[0]] == &op || (ch.tail[1] >= 0 && &h->ops[ch.tail[1]] == &op)) return Y4_OK;   // ran with its head
         }
@@ -667,6 +689,22 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
             pd.fin2 = buf_ptr(h, to.out2, img0); pd.fin2_cstride = to.out2.cstride; pd.fin2_coff = to.out2.coff;
         }
         return conv2d_launch(&d, h->act + h->zero_off, s, nullptr, &pd);
+    }
+    if (chain && chain->alt_of >= 0) {
+        // this op (64 -> 64) feeds the conv over Concatenate([its output, route]) in registers; its own output is not stored
+        const Op& to = h->ops[chain->tail[0]];
+        const Layer& TL = h->layers[to.conv];
+        ConvChainDesc cd{};
+        cd.ntail = 2; cd.concat_only = 1; cd.store_x = 0;
+        cd.tail[1].w = h->wts + TL.tail_off;
+        cd.tail[1].scale = (const float*)(h->wts + TL.scale_off);
+        cd.tail[1].shift = (const float*)(h->wts + TL.shift_off);
+        cd.tail[1].cout = TL.d.cout;
+        cd.tail[1].src2 = buf_ptr(h, to.in, img0);
+        cd.tail[1].src2_cstride = to.in.cstride;
+        cd.tail[1].src2_coff = to.in.coff + 64;
+        cd.fin = buf_ptr(h, to.out, img0); cd.fin_cstride = to.out.cstride; cd.fin_coff = to.out.coff;
+        return conv2d_launch(&d, h->act + h->zero_off, s, &cd);
     }
     if (chain) {
         ConvChainDesc cd{};
@@ -1110,6 +1148,9 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
             Chain& ch = h->chains[ci];
             auto mirror = [&]() { if (h2) { h2->chains[ci].tile = ch.tile; h2->chains[ci].enabled = ch.enabled; } };
             if (rc != Y4_OK) break;
+            // an alternative run is timed as if its parent's head sat in a residual-block kernel (those are off until pass 4)
+            h->force_chain = ch.alt_of >= 0 ? (int)ci : -1;
+            if (h2) h2->force_chain = h->force_chain;
             float separate = best_ms[ch.head] + best_ms[ch.tail[0]] + (ch.tail[1] >= 0 ? best_ms[ch.tail[1]] : 0.f);
             float best = 1e30f;
             int best_tile = 0;
@@ -1161,6 +1202,8 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
             ch.enabled = fused_ok && t_fused < t_sep;
             mirror();
         }
+    h->force_chain = -1;
+    if (h2) h2->force_chain = -1;
     // pass 3: the stage kernel (convs 2..7 in one launch) head to head against the same ops as tuned above
     two = h2 && (pair_passes & 4);
     if (rc == Y4_OK && h->stage_first >= 0 && h->stage_on) {
@@ -1366,7 +1409,7 @@ static bool op_launches(y4_handle h, int oi) {
     if (h->stage_active() && oi >= h->stage_first && oi <= h->stage_last) return oi == h->stage_first;
     if (h->fuse_chains)
         for (const Chain& ch : h->chains)
-            if (ch.enabled && !h->res_of(ch.head, nullptr) && (ch.tail[0] == oi || ch.tail[1] == oi)) return false;
+            if (h->chain_active(ch) && (ch.tail[0] == oi || ch.tail[1] == oi)) return false;
     return true;
 }
 
