@@ -177,7 +177,9 @@ int y4_set_stem_fusion(y4_handle h, int on);
  * a negative Y4_E* code on error.  While on, y4_get_conv_output of a conv inside a run (not its last) reads a
  * tensor that is not materialised.  y4_autotune then also decides per run, by measurement, whether it executes as
  * one kernel or as separate ones; y4_get_tiles reports a fused run's head conv as MINUS its tile id (y4_set_tiles
- * accepts the same encoding; > 0 there means separate kernels, 0 fused with the built-in tile). */
+ * accepts the same encoding; > 0 there means separate kernels, 0 fused with the built-in tile).  One run is an ALTERNATIVE:
+ * "1x1 conv 64 -> 64 -> 1x1 conv over Concatenate([., route])" (custom_layers.py:66-69) is in force only while the three-conv run
+ * it is the tail of cannot exist because that run's 3x3 conv executes inside a residual-block kernel (y4_set_res_fusion). */
 int y4_set_chain_fusion(y4_handle h, int on);
 
 /* Scheduling knob (16-bit dtypes; results unchanged): run the whole first CSP stage -- convs 2..7, reference
