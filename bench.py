@@ -55,11 +55,11 @@ def cpu_model():
         return "unknown", os.cpu_count() or 0
 
 
-def cpu_baseline(size, ncls, ws, cfg, budget_s=10.0):
+def cpu_baseline(size, ncls, ws, cfg, batch=32, runs=3):
     """the reference's tf.keras CPU predict() cannot run anywhere we run (no TensorFlow), so the figure
     beside the GPU number is a PROXY -- the oracle (torch-CPU fp32 / oneDNN forward + NumPy decode/NMS, kind 'port') on the
-    GPU box's host cores: batch 1, and the largest batch <= 32 whose 1 warm-up + 3 timed runs fit ~`budget_s` seconds
-    (estimated from the batch-1 time; batch 32 itself needs > 10 s per run on these hosts and is reported only if it fits)."""
+    GPU box's host cores, measured as SURVEY.md section 8(d) prescribes: batch `batch` (32, the configuration the metric is
+    quoted on) and batch 1, 1 warm-up + `runs` (3) timed runs each.  `value` is the batch-`batch` rate."""
     import torch
     from yolo4hip import weights as W
     from oracle import forward as OF, decode_nms as OD
@@ -69,26 +69,29 @@ def cpu_baseline(size, ncls, ws, cfg, budget_s=10.0):
     torch.set_num_threads(cores)
     model, hw_threads = cpu_model()
 
-    def timed(nimg, runs):
+    def timed(nimg):
         imgs = W.synth_images(nimg, size, seed=0)
         def once():
             heads = OF.yolo_model_forward(imgs, ws, ncls)
             return OD.inference_from_heads(heads, ncls, cfg["anchors"], cfg["xyscale"], size)
         once()                                # warm-up (oneDNN primitive creation, page-in)
-        t0 = time.perf_counter()
+        ts = []
         for _ in range(runs):
+            t0 = time.perf_counter()
             once()
-        return time.perf_counter() - t0
-    dt1 = timed(1, 3)
-    per_img = dt1 / 3
-    nb = max(2, min(32, int(budget_s / (4 * per_img * 0.6))))      # batches amortise: ~0.6x the batch-1 cost per image
-    dtb = timed(nb, 3)
-    return {"value": round(nb * 3 / dtb, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            ts.append(time.perf_counter() - t0)
+        return ts
+    t1 = timed(1)
+    tb = timed(batch)
+    return {"value": round(batch * runs / sum(tb), 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "label": "CPU restatement (proxy for tf.keras CPU; the reference's own CPU path needs TensorFlow, absent here)",
             "cpu_model": model, "hw_threads": hw_threads,
-            "batch": nb, "batch1_value": round(3 / dt1, 4),
-            "sample": f"3 runs x {nb} images (and 3 x 1 image) {size}x{size}x3, {ncls} classes, fp32 torch-CPU(oneDNN) forward "
-                      f"+ NumPy decode/NMS (oracle/), 1 warm-up run each; {dtb + dt1:.1f} s of timed CPU work on {cores} threads"}
+            "batch": batch, "runs_s": [round(t, 3) for t in tb],
+            "batch1_value": round(runs / sum(t1), 4), "batch1_runs_s": [round(t, 3) for t in t1],
+            "sample": f"{runs} timed runs x {batch} images and {runs} x 1 image, {size}x{size}x3, {ncls} classes, fp32 "
+                      f"torch-CPU(oneDNN) forward + NumPy decode/NMS (oracle/), 1 warm-up run each (SURVEY.md 8(d)); "
+                      f"{sum(tb) + sum(t1):.1f} s of timed CPU work on {cores} threads (oneDNN is fastest near 32 threads on "
+                      f"this host and collapses at all {hw_threads})"}
 
 
 def committed_traffic(args, fused_stem, chained, staged, res_mask, tiles):
@@ -154,6 +157,13 @@ def parse_args(argv):
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=32,
+                    help="batch of the CPU proxy baseline (SURVEY.md 8(d): 32 and 1; 1 warm-up + 3 timed runs each, ~55 s of host time)")
+    ap.add_argument("--stop-after-conv", type=int, default=71,
+                    help="last conv of the backbone-only passes (`roofline.backbone_wall`): the forward cut behind this conv "
+                         "(y4_forward_until), wall-clock timed with one stream and with --in-flight batches in flight; 71 = "
+                         "CSPDarknet53 proper (reference custom_layers.py:100-124); -1 skips the passes")
+
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristic instead of measuring")
     ap.add_argument("--tune-reps", type=int, default=3)
     ap.add_argument("--pair-passes", type=int, default=12,
@@ -167,7 +177,9 @@ def parse_args(argv):
     ap.add_argument("--retune", action="store_true",
                     help="autotune on this box even when a tuned schedule ships with the package for this shape "
                          "(yolo4hip/schedules/: the headline shape's is the tile set profiles/r03 was profiled with)")
-    ap.add_argument("--subbatch", type=int, default=0, help="images per sub-batch for the early layers (0 = whole batch)")
+    ap.add_argument("--subbatch", type=int, default=0,
+                    help="images per sub-batch for the early layers (0 = whole batch); sub-batching and workspace aliasing exclude each "
+                         "other (y4_set_subbatch refuses), so a run with --subbatch uses the plain, un-aliased workspace")
     ap.add_argument("--sub-last-conv", type=int, default=16)
     ap.add_argument("--no-stem-fusion", action="store_true", help="run convs 0 and 1 as two kernels (c0 through HBM)")
     ap.add_argument("--no-chain-fusion", action="store_true", help="run the 3x3+Add -> 1x1 -> 1x1 runs as separate kernels")
@@ -194,20 +206,37 @@ def dry_run(args):
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     lo, hi = D.shard_range(args.batch * world, rank, world)
-    blocks = []
+    # what every rank does before its first library call in the real run: bind its own device (recorded, not executed, here)
+    bound = f"cuda:{local_rank}"
+    if os.environ.get("Y4_DRY_SLOW_RANK0"):          # rank 0 "synthesises the weights" while the others wait in the broadcast
+        import torch
+        blob = torch.zeros(1 << 16, dtype=torch.uint8)
+        if rank == 0:
+            time.sleep(float(os.environ["Y4_DRY_SLOW_RANK0"]))
+            blob += 7
+        D.broadcast_bytes(blob, 0)
+        assert int(blob[123]) == 7
+    local, own = [], []
     for _ in range(args.blocks):
         D.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            time.sleep(0.001)
+            time.sleep(0.001 * (1 + (rank == world - 1 and os.environ.get("Y4_DRY_STRAGGLER") == "1")))
+        own.append(time.perf_counter() - t0)                 # this rank's own K steps, before it waits for the others
         D.barrier()
-        blocks.append(D.max_over_ranks(time.perf_counter() - t0))
+        local.append(time.perf_counter() - t0)
+    blocks = D.max_over_ranks(local)
+    my_ms = statistics.median(own) / args.steps * 1e3
+    rank_ms, devices = D.gather_objects(my_ms), D.gather_objects(bound)
     if rank == 0:
         dt = statistics.median(blocks)
         print(json.dumps({"metric": METRIC + " [DRY RUN: no GPU work]", "value": round(args.batch * world * args.steps / dt, 2),
                           "unit": "images/sec", "n_gpus": dist.get_world_size() if dist.is_initialized() else 1,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+                          "rank_ms_per_step": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4),
+                                               "per_rank": [round(v, 4) for v in rank_ms]},
+                          "devices": devices,
                           "data": "dry-run (no GPU work)", "config": {"workload": "launcher self-test", "shard": [lo, hi]}}),
               flush=True)
     D.barrier()
@@ -222,6 +251,8 @@ def main():
         sys.exit(self_launch(args.gpus, argv))
     if args.batch < 1 or args.steps < 1 or args.blocks < 1 or args.gpus < 1:
         raise SystemExit("bench.py: --batch, --steps, --blocks and --gpus must be >= 1")
+    if args.subbatch > 0:
+        args.alias_workspace = False       # see --subbatch
     if args.dry_run:
         return dry_run(args)
 
@@ -344,7 +375,7 @@ def main():
     torch.cuda.synchronize()
     if depth == 1:                                           # one stream: the events sit in the timed blocks themselves
         eng.timing_begin(min(args.steps * args.blocks, 4096), coarse=not args.per_op)
-    local = []
+    local, own = [], []
     for _ in range(args.blocks):
         D.barrier()
         torch.cuda.synchronize()
@@ -352,6 +383,7 @@ def main():
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
+        own.append(time.perf_counter() - t0)               # this rank's own K steps, before it waits for the others
         D.barrier()
         torch.cuda.synchronize()
         local.append(time.perf_counter() - t0)              # nothing but the K steps between the two brackets
@@ -376,6 +408,32 @@ def main():
         ops, nrec = eng.timing_end()
     import hashlib
     digest = hashlib.sha256(host.numpy().tobytes()).hexdigest() if same else "SLOTS DIFFER"   # outputs of the last step
+    # ---- the backbone on its own, from WALL time, in both regimes: the forward cut behind conv
+    # --stop-after-conv (71: CSPDarknet53 proper), K steps with one stream, then K steps with `depth` batches in flight
+    backbone_wall = None
+    if args.stop_after_conv >= 0:
+        def backbone_pass(nslots):
+            for k in range(nslots):                                  # warm-up, one per slot
+                with torch.cuda.stream(fl.streams[k]):
+                    fl.engines[k].forward_until_device(slot_imgs[k], args.stop_after_conv)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                k = i % nslots
+                with torch.cuda.stream(fl.streams[k]):
+                    fl.engines[k].forward_until_device(slot_imgs[k], args.stop_after_conv)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / args.steps * 1e3
+        bb_flops = sum(c.flops_per_image for c in plan.convs[:args.stop_after_conv + 1]) * (hi - lo)
+        peak_tf = MFMA_PEAK_TFLOPS[args.dtype]
+        backbone_wall = {"last_conv": args.stop_after_conv, "flops_per_step": bb_flops, "steps": args.steps,
+                         "timing": "wall clock around K y4_forward_until calls, synchronize on both sides, rank 0's own GPU"}
+        for name, nslots in (("one_stream", 1),) + ((("in_flight_%d" % depth, depth),) if depth > 1 else ()):
+            ms = min(backbone_pass(nslots) for _ in range(3))        # best of 3 short passes (each K steps)
+            backbone_wall[name] = {"ms_per_step": round(ms, 4), "frac": round(bb_flops / (ms * 1e-3) / 1e12 / peak_tf, 4)}
+    # every rank's own median block (a straggler must be visible the first time this runs on a real node)
+    my_ms = statistics.median(own) / args.steps * 1e3
+    rank_ms = [float(v) for v in D.gather_objects(my_ms)]
 
     if rank == 0:
         dt = statistics.median(blocks)
@@ -416,6 +474,10 @@ def main():
                        "sharding": f"batch split over {world} rank(s), no data-path collective"},
             "outputs_sha256": digest,
             "blocks_ms_per_step": [round(b / args.steps * 1e3, 4) for b in blocks],
+            "rank_ms_per_step": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4),
+                                 "per_rank": [round(v, 4) for v in rank_ms],
+                                 "what": "each rank's own K steps (median block, stopped BEFORE the closing barrier) / K; ms_per_step above is "
+                                         "the barrier-bracketed block, max over ranks"},
             "timing": f"median of {args.blocks} blocks of {args.steps} steps, each barrier+synchronize bracketed, max over ranks; "
                       f"{depth} batch(es) in flight per GPU (step i on HIP stream / workspace i % {depth}, shared weights)",
             "in_flight": depth, "schedule": schedule_src,
@@ -426,11 +488,14 @@ def main():
                          "frac": round(achieved / peak, 4),
                          "backbone_frac": frac_of(backbone_flops, backbone_ms),
                          "backbone_ms_per_step": round(backbone_ms, 4),
+                         "backbone_wall": backbone_wall,
                          "whole_forward_frac": frac_of(fwd_flops, fwd_ms),
                          "end_to_end_frac": round(n_img / dt * plan.flops_per_image / 1e12 / peak / world, 4),
                          "timed_region_frac": round(conv_flops / (dt / args.steps) / 1e12 / peak, 4),
                          "frac_definitions": "frac: conv family FLOPs / its HIP-event time; backbone_frac: convs 0..71 (CSPDarknet53, "
-                                             "73.696 GFLOP/image at 608) / stem + conv segment up to conv 71; whole_forward_frac: all 110 "
+                                             "73.696 GFLOP/image at 608) / stem + conv segment up to conv 71 (HIP events, one stream); "
+                                             "backbone_wall: the same FLOPs / WALL time of y4_forward_until(conv 71) alone, one stream and "
+                                             "with the timed region's batches in flight; whole_forward_frac: all 110 "
                                              "convs / stem + convs + SPP; end_to_end_frac: all 110 convs x images/s (per GPU) / peak; timed_region_frac: the conv "
                                              "family's FLOPs / the WALL time of a step in the timed blocks (a lower bound on the family inside the "
                                              "timed region: that time also holds stem, SPP, decode, NMS and the copy of the results)",
@@ -460,7 +525,7 @@ def main():
                 print(f"{name:8s} {ms:8.4f} ms  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.1f} TFLOP/s", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             ws = ws_holder.get("ws") or W.synth_weights(plan, seed=0)
-            line["cpu_baseline"] = cpu_baseline(args.size, args.classes, ws, cfg)
+            line["cpu_baseline"] = cpu_baseline(args.size, args.classes, ws, cfg, batch=args.cpu_batch)
         print(json.dumps(line), flush=True)
     D.barrier()
     if dist.is_available() and dist.is_initialized():

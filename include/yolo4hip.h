@@ -107,6 +107,11 @@ int y4_forward(y4_handle h, const float* imgs_nhwc_dev, int n, void* stream);
  * PCIe / HBM at 3 B per pixel.  Bit-identical to y4_forward on float32(double(v) / 255.) for every dtype.
  * Frames of another size go through y4_resize_u8 (cv2.resize's uint8 INTER_LINEAR arithmetic) first. */
 int y4_forward_u8(y4_handle h, const uint8_t* imgs_nhwc_u8_dev, int n, void* stream);
+/* y4_forward cut behind conv `last_conv` (0-based, the reference's creation order): the ops up to and including the launch
+ * that computes it.  last_conv = 71 is `cspdarknet53` proper -- the five CSP stages, reference custom_layers.py:100-124, before the
+ * SPP block's convs -- which bench.py times on its own (`backbone` in its line).  Y4_EINVAL when the conv does not end a launch
+ * under the current fusion settings (a run that continues behind it is never cut). */
+int y4_forward_until(y4_handle h, const float* imgs_nhwc_dev, int n, int last_conv, void* stream);
 /* Dense float32 copies of the three raw heads, [n,g,g,3*(C+5)] each, as Keras returns them. */
 int y4_get_heads(y4_handle h, int n, float* out_s_dev, float* out_m_dev, float* out_l_dev, void* stream);
 /* Inverse of y4_get_heads: load dense float32 raw heads [n,g,g,3*(C+5)] into the workspace, so that
@@ -154,8 +159,14 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream);
 int y4_autotune_pair(y4_handle h, y4_handle h2, int n, int reps, void* stream, void* stream2, int pair_passes);
 int y4_get_tiles(y4_handle h, int32_t* tiles, int cap);
 /* Restore a tile choice saved from y4_get_tiles (one entry per conv index; an id that does not fit its layer makes
- * the next forward fail with Y4_EINVAL rather than compute anything different). */
+ * the next forward fail with Y4_EINVAL rather than compute anything different).  The head conv of a fused run (see
+ * y4_set_chain_fusion) carries two choices in its entry: -(run tile + 1000 * the conv's own tile for when the run is not in
+ * force); a plain -t (older files) leaves the own tile as it is, so y4_set_tiles(y4_get_tiles()) restores a handle exactly. */
 int y4_set_tiles(y4_handle h, const int32_t* tiles, int count);
+/* Every scheduling choice of `src` -> `dst`, a second handle created from the same configuration (the sibling that runs a second
+ * batch in flight): tiles, each run's state, stage-kernel and residual-block verdicts, the fusion switches, sub-batching.
+ * (No reference counterpart: TensorFlow's executor schedules the reference's graph; models.py:113,159.) */
+int y4_copy_schedule(y4_handle src, y4_handle dst);
 
 /* Scheduling knob (results unchanged): run the ops up to and including conv `last_conv` over `images` images at a
  * time instead of the whole batch, so that the large early activations of a sub-batch are still resident in the

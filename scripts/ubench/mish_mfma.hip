@@ -1,0 +1,162 @@
+// MFMA || Mish co-issue microbenchmark for gfx950 (what bounds csp_stage_kernel).
+// One 512-thread workgroup per CU (2 waves per SIMD).  Per iteration a wave issues 32 v_mfma_f32_16x16x32_bf16 (8 accumulators x
+// 4 k-steps) and the BN + Mish + bf16 pack of the PREVIOUS iteration's 8 accumulators (32 values per lane), the packed result
+// being the next iteration's B operand (the register chain of the stage kernel).
+//   MODE 0  MFMAs, then Mish (what hipcc does with the source order)            lock-step: s_barrier per iteration
+//   MODE 1  the same, waves 4..7 half an iteration out of phase (Mish first)
+//   MODE 2  one MFMA, five VALU, ... pinned with sched_group_barrier
+//   MODE 3  MFMAs only          MODE 4  Mish only
+//   SCALAR = 1: v_fma_f32 forms instead of v_pk_fma_f32;  BAR = 0: no barrier (free-running waves)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+template <bool SCALAR>
+__device__ __forceinline__ void mish4(const f32x4& a, const float* sc, const float* sh, float* out) {
+    if (SCALAR) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = fmaf(a[r], sc[r], sh[r]);
+            const float e = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+            const float rr = __builtin_amdgcn_rcpf(fmaf(e, fmaf(e, 0.5f, 1.f), 1.f));
+            out[r] = fmaf(-x, rr, x);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+            const f32x2 x = __builtin_elementwise_fma(f32x2{a[r], a[r + 1]}, f32x2{sc[r], sc[r + 1]}, f32x2{sh[r], sh[r + 1]});
+            const f32x2 t = x * 1.4426950408889634f;
+            const f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            const f32x2 dh = __builtin_elementwise_fma(e, __builtin_elementwise_fma(e, f32x2{0.5f, 0.5f}, f32x2{1.f, 1.f}), f32x2{1.f, 1.f});
+            const f32x2 rr = {__builtin_amdgcn_rcpf(dh.x), __builtin_amdgcn_rcpf(dh.y)};
+            const f32x2 y = __builtin_elementwise_fma(-x, rr, x);
+            out[r] = y.x; out[r + 1] = y.y;
+        }
+    }
+}
+
+template <int MODE, bool SCALAR, bool BAR>
+__global__ __launch_bounds__(512, 1) void k(float* out, const u32x4* win, int iters) {
+    extern __shared__ char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32x4 w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = win[j * 64 + lane];
+    float sc[16], sh[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sc[i] = 1.f + 0.01f * i; sh[i] = 0.001f * lane; }
+    u32x4 x[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) x[s] = win[512 + s * 64 + lane];
+    f32x4 accP[8], accN[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accP[j] = f32x4{0.1f * j, 0.2f, 0.3f, 0.4f};
+    const bool late = MODE == 1 && wave >= 4;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) accN[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 xn[4];
+        auto mfmas = [&]() {
+            if (MODE == 4) return;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    accN[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]), __builtin_bit_cast(bf16x8, x[s]), accN[j], 0, 0, 0);
+        };
+        auto mishes = [&]() {
+            if (MODE == 3) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) xn[s] = x[s];
+                return;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v[8];
+                mish4<SCALAR>(accP[2 * c], sc + (c & 1) * 8, sh + (c & 1) * 8, v);
+                mish4<SCALAR>(accP[2 * c + 1], sc + (c & 1) * 8 + 4, sh + (c & 1) * 8 + 4, v + 4);
+                const f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+                xn[c] = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
+            }
+        };
+        if (MODE == 2) {
+            mfmas(); mishes();
+            // 32 MFMAs, 160 VALU (96 plain + 64 transcendental): five VALU behind every MFMA
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x402, SCALAR ? 8 : 5, 0);
+            }
+        } else if (late) {
+            mishes();
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas();
+        } else {
+            mfmas();
+            __builtin_amdgcn_sched_barrier(0);
+            mishes();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (MODE == 4) {            // Mish only: the next input is the (unpacked) output, so nothing can be dropped
+                const u32x4 c = xn[j >> 1];
+                const int h = (j & 1) * 2;
+                accP[j] = f32x4{__uint_as_float(c[h] << 16), __uint_as_float(c[h] & 0xffff0000u), __uint_as_float(c[h + 1] << 16), __uint_as_float(c[h + 1] & 0xffff0000u)};
+            } else accP[j] = accN[j];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) x[s] = xn[s];
+        if (BAR) __builtin_amdgcn_s_barrier();
+    }
+    float s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += accP[j][0] + accP[j][1] + accP[j][2] + accP[j][3];
+    s += __uint_as_float(x[0][0]);
+    if (s == 12345.678f) out[0] = s;
+}
+
+template <int MODE, bool SCALAR, bool BAR> int run(const char* name, float* d, const u32x4* w) {
+    const int iters = 4000, blocks = 256;
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    CHECK(hipFuncSetAttribute((const void*)k<MODE, SCALAR, BAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    hipLaunchKernelGGL((k<MODE, SCALAR, BAR>), dim3(blocks), dim3(512), 100 * 1024, 0, d, w, 50);
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k<MODE, SCALAR, BAR>), dim3(blocks), dim3(512), 100 * 1024, 0, d, w, iters);
+    CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    // per SIMD and iteration: 2 waves x (32 MFMAs, 32 Mish values per lane)
+    const double ns_it = ms * 1e6 / iters;
+    printf("%-58s %7.1f ns per iteration per SIMD pair  (2 x 32 MFMA = %.0f ns at 16 cyc & 2.1 GHz; per Mish value-lane %.2f ns)\n", name, ns_it,
+           64 * 16 / 2.1, ns_it / 64);
+    return 0;
+}
+int main() {
+    float* d; CHECK(hipMalloc(&d, 1024));
+    u32x4* w; CHECK(hipMalloc(&w, 768 * 16));
+    uint32_t* h = (uint32_t*)malloc(768 * 16);
+    for (int i = 0; i < 768 * 4; ++i) h[i] = 0x3c003c00u + ((i * 2654435761u) >> 20 & 0x00ff00ffu);    // bf16 pairs near 0.0078
+    CHECK(hipMemcpy(w, h, 768 * 16, hipMemcpyHostToDevice));
+    run<3, false, true>("MFMAs only, barrier", d, w);
+    run<3, false, false>("MFMAs only, free", d, w);
+    run<4, false, true>("Mish only (packed), barrier", d, w);
+    run<4, false, false>("Mish only (packed), free", d, w);
+    run<4, true, false>("Mish only (scalar), free", d, w);
+    run<0, false, true>("MFMAs then Mish (packed), lock-step", d, w);
+    run<0, false, false>("MFMAs then Mish (packed), free", d, w);
+    run<0, true, true>("MFMAs then Mish (scalar), lock-step", d, w);
+    run<0, true, false>("MFMAs then Mish (scalar), free", d, w);
+    run<1, false, true>("half-phase stagger (packed), barrier", d, w);
+    run<1, true, true>("half-phase stagger (scalar), barrier", d, w);
+    run<2, false, true>("interleaved in-wave (packed), barrier", d, w);
+    run<2, false, false>("interleaved in-wave (packed), free", d, w);
+    run<2, true, true>("interleaved in-wave (scalar), barrier", d, w);
+    run<2, true, false>("interleaved in-wave (scalar), free", d, w);
+    return 0;
+}

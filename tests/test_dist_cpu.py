@@ -28,7 +28,7 @@ def _worker(rank, world, port, ret):
     D.broadcast_bytes(blob, src=0)
     ok_bcast = bool((blob.view(torch.int32) == torch.arange(4096, dtype=torch.int32)).all())
     # 2. batch sharding: every rank builds ITS slice of the global synthetic batch
-    n_total = 6
+    n_total = 3 * world
     lo, hi = D.shard_range(n_total, rank, world)
     mine = W.synth_images(hi - lo, 16, seed=3, first_index=lo)
     # stand-in for per-image results: [n,4] + valid[n]
@@ -39,7 +39,7 @@ def _worker(rank, world, port, ret):
     ok_gather = np.array_equal(g[0], full) and np.array_equal(g[1], np.arange(n_total, dtype=np.int32))
     # 2b. a batch that does not divide by the world size: shards of 3 and 2 images (the short shard is NOT the last
     #     rows of the padded gather, so stripping must be per rank)
-    n_odd = 5
+    n_odd = 2 * world + 1
     lo2, hi2 = D.shard_range(n_odd, rank, world)
     g2 = D.gather_results([torch.arange(lo2, hi2, dtype=torch.int32),
                            torch.arange(lo2, hi2, dtype=torch.float32).view(-1, 1).repeat(1, 3)], n_odd)
@@ -48,17 +48,37 @@ def _worker(rank, world, port, ret):
     mx = D.max_over_ranks(10.0 + rank)
     # the bench's per-block times: taken locally, reduced element-wise with ONE all_reduce after the last timed block
     mxs = D.max_over_ranks([1.0 + rank, 5.0 - rank, 3.0])
+    objs = D.gather_objects({"rank": rank, "dev": f"cuda:{lr}"})
+    assert [o["rank"] for o in objs] == list(range(world)) and objs[rank]["dev"] == f"cuda:{rank}"
+    # 3. an uneven global batch over the whole world (world 8: 35 images -> shards of 5,5,5,4,...): every image exactly once
+    n_u = 4 * world + 3
+    lo3, hi3 = D.shard_range(n_u, rank, world)
+    g3 = D.gather_results([torch.arange(lo3, hi3, dtype=torch.int32)], n_u)
+    assert np.array_equal(g3[0], np.arange(n_u, dtype=np.int32)) and 0 <= (hi3 - lo3) - n_u // world <= 1
+    # 4. fewer images than ranks: the last rank's shard is EMPTY and still takes part in the gather
+    lo4, hi4 = D.shard_range(world - 1, rank, world)
+    g4 = D.gather_results([torch.arange(lo4, hi4, dtype=torch.int32), torch.zeros((hi4 - lo4, 100, 4))], world - 1)
+    assert np.array_equal(g4[0], np.arange(world - 1, dtype=np.int32)) and g4[1].shape == (world - 1, 100, 4)
     D.barrier()
     ret[rank] = (ok_bcast, ok_gather, mx, mxs)
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_gloo_protocol():
-    world, port = 2, _free_port()
+def _protocol(world):
+    port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert len(ret) == world
     for rank in range(world):
         ok_bcast, ok_gather, mx, mxs = ret[rank]
-        assert ok_bcast and ok_gather and mx == 11.0 and mxs == [2.0, 5.0, 3.0]
+        assert ok_bcast and ok_gather and mx == 9.0 + world and mxs == [float(world), 5.0, 3.0]
+
+
+def test_two_rank_gloo_protocol():
+    _protocol(2)
+
+
+def test_eight_rank_gloo_protocol():
+    """The shape of the driver's 8-GPU launch (one process per GPU of one node), on CPU."""
+    _protocol(8)

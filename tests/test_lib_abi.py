@@ -126,8 +126,33 @@ def test_every_shipped_schedule_is_accepted_by_the_library():
         ext.check(lib.y4_set_tiles(h, tiles, len(s["tiles"])))
         back = (C.c_int32 * 110)()
         ext.check(lib.y4_get_tiles(h, back, 110))
-        # what the handle reports equals the file wherever the file's entry is in force (a chain's tails keep their own ids)
-        assert sum(1 for a, b in zip(s["tiles"], back) if a != b) <= 110 and all(abs(t) <= lib.y4_conv_tile_count() for t in s["tiles"])
+        # the handle reports exactly the file, and what it reports restores it exactly (a run's head carries its run tile AND its
+        # own tile in one entry): set(get()) is the identity, also on a fresh handle with the run switched off before
+        assert list(back) == [int(t) for t in s["tiles"]], [(i, a, b) for i, (a, b) in enumerate(zip(s["tiles"], back)) if a != b]
+        h2 = C.c_void_p()
+        ext.check(lib.y4_create(C.byref(cfg), C.byref(h2)))
+        ext.check(lib.y4_copy_schedule(h, h2))
+        back2 = (C.c_int32 * 110)()
+        ext.check(lib.y4_get_tiles(h2, back2, 110))
+        assert list(back2) == list(back) and lib.y4_get_stage_fusion(h2) == lib.y4_get_stage_fusion(h) \
+            and lib.y4_get_res_fusion(h2) == lib.y4_get_res_fusion(h)
+        # a run head's own tile survives the round trip: give conv 15 (the alternative run's head) one, with the run in force
+        if back[15] < 0:
+            probe = list(back)
+            probe[15] = -((-back[15]) % 1000 + 1000 * 7)
+            arr = (C.c_int32 * 110)(*probe)
+            ext.check(lib.y4_set_tiles(h, arr, 110))
+            ext.check(lib.y4_get_tiles(h, back2, 110))
+            assert list(back2) == probe
+            ext.check(lib.y4_set_tiles(h2, back2, 110))
+            back3 = (C.c_int32 * 110)()
+            ext.check(lib.y4_get_tiles(h2, back3, 110))
+            assert list(back3) == probe
+            ext.check(lib.y4_set_tiles(h, tiles, len(s["tiles"])))       # plain -t leaves the own tile: still 7
+            ext.check(lib.y4_get_tiles(h, back2, 110))
+            assert back2[15] == -((-s["tiles"][15]) % 1000 + 7000)
+        assert lib.y4_copy_schedule(h, h) < 0
+        lib.y4_destroy(h2)
         assert lib.y4_set_stage_fusion(h, int(s["stage_fusion"])) == int(s["stage_fusion"])
         ext.check(lib.y4_set_res_fusion_mask(h, int(s["res_fusion_mask"])))
         assert lib.y4_get_res_fusion(h) == s["res_fusion_mask"]

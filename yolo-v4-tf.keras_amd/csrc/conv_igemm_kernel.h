@@ -75,6 +75,11 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     constexpr int STAGE = (BM + BN) * BKB;
     constexpr int KSTEPS = BKB / 64;        // MFMA k-steps (4 chunks each) per tile
     static_assert(BM % 16 == 0 && (BN % RPI == 0 || (RPI % BN == 0 && (BN * CPR) % 64 == 0)), "tile rows vs rows-per-iteration");
+    // weight_touch() parks its dwords in `smem + wave_lds`, i.e. in rows wave*8 .. +7 of stage 0's A region, and relies on THIS
+    // wave's own j = 0 activation load of stage(0) overwriting them later (a wave's loads retire in order).  That load exists for
+    // every wave only while no wave's first row lies past the tile (r0 < BM for all waves <=> RPI <= BM); with RPI > BM the
+    // scratch of the upper waves would sit in rows that ANOTHER wave's weight load fills -- a cross-wave LDS race.
+    static_assert(RPI <= BM, "weight_touch scratch must be a piece the same wave's first stage load overwrites");
     static_assert(MREP >= 1 && NREP >= 1, "wave tile");
     constexpr int LPT = A_IT + B_IT;        // LDS-DMA instructions a wave issues per stage
     static_assert(SN >= 2 && SN <= 4 && (SN == 2 || !B_PART), "deep pipelines need uniform weight loads per wave");

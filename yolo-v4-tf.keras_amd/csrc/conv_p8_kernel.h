@@ -171,6 +171,8 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(p.wt, p.wt_bytes);
     const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
+    // (the touch scratch smem + wave_lds is region 0 / stage 0's piece of THIS wave: issue_a(0, 0) below, which every one of the
+    //  eight waves issues -- all waves stage every region -- overwrites it in order)
     if (p.touch != 0) weight_touch(rs_wt, smem + wave_lds, n0 * p.K * ES, 256 * p.K * ES, wave, 8, lane);     // conv_common.h
     const int nk = p.K / BK;
     // staging cursor: the K-tile whose regions are being issued (tap, byte offset of c0, byte offset of k in the weights)

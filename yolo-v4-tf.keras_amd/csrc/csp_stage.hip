@@ -28,6 +28,19 @@
 #ifndef CS_ABL
 #define CS_ABL 0
 #endif
+#ifndef CS_PRIO
+// 1: "leapfrog" priorities -- a wave lowers its s_setprio level as it moves through the segments of a barrier interval, so the wave
+// of a SIMD that is BEHIND outranks its partner (the hardware's own tie-break is age: the older wave of a SIMD runs unimpeded and
+// the younger one gets the leftover VALU / transcendental slots, then finishes alone at a single wave's issue rate).
+// 2: waves 4..7 at priority 1 throughout (the mirror image of the default).
+#define CS_PRIO 1
+#endif
+#ifndef CS_LX
+#define CS_LX 1     // 1: the halo tile's per-lane offsets and border flags are computed once per workgroup, not once per tile
+#endif
+#ifndef CS_EXTRA
+#define CS_EXTRA 1  // 1: the five halo-ring fragments on waves 0..3 (wave 0 takes two) instead of waves 0..4
+#endif
 #ifndef CS_VMCNT
 // 0: the tile boundary drains everything.  4 would let the previous tile's 4 output stores stay in flight (measured: 583 ->
 // 578 us), but it relies on stores and LDS-DMA loads retiring in issue order RELATIVE TO EACH OTHER on one vmcnt counter,
@@ -37,7 +50,28 @@
 
 namespace y4 {
 
+#ifdef CS_TRACE
+// In-kernel phase trace (kernel experiments only; scripts/stage_trace.py): workgroup CS_TR_WG records s_memtime per wave at
+// fixed points of its tiles CS_TR_T0 .. +3 into cs_trace_buf[tile][wave][point]; y4_cs_trace_read() copies it out.
+__device__ unsigned long long cs_trace_buf[4 * 8 * 16];
+#define CS_TR_WG 8
+#define CS_TR_T0 3
+#define CS_POINT(P)                                                                                         \
+    do {                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (tr_on) asm volatile("s_memtime %0" : "=s"(tr_t[P]));                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    } while (0)
+#else
+#define CS_POINT(P)
+#endif
+
 constexpr int CS_ACT = CS_ABL == 1 ? Y4_ACT_LEAKY : Y4_ACT_MISH;
+#if CS_PRIO == 1
+#define CS_SEG(K) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(K); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CS_SEG(K)
+#endif
 
 // ---- LDS map (bytes).  Weight fragments are "fragment ordered" (pack_frag_kernel): [(kstep*NREP + j)*64 + lane][8].
 constexpr int CS_W3 = 0;                        // 64 x 64      : 2 k-steps x 4 fragments x 1 KB
@@ -129,6 +163,33 @@ __global__ __launch_bounds__(64 * CS_WAVES, 1) void csp_stage_kernel(const CspSt
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
     // halo'd tile of x -> X1: one wave-wide piece = 8 rows x 128 B; LDS-DMA writes lane-linearly, so the XOR swizzle of
     // the 16-byte chunk index is applied to the SOURCE address
+#if CS_LX
+    // per piece k of this wave (u = wave + 8k): byte offset of the lane's 16 bytes relative to halo pixel (0, 0) of the tile, with
+    // the lane's border flags in the four low bits (always zero in an offset): 1 = halo row 0, 2 = halo row 17, 4 = halo column 0,
+    // 8 = halo column 17.  Rows past the 324 halo pixels get every flag and are always out of range.
+    constexpr int CS_NPIECE = (CS_HROWS / 8 + CS_WAVES - 1) / CS_WAVES;
+    int lx_rel[CS_NPIECE];
+#pragma unroll
+    for (int k = 0; k < CS_NPIECE; ++k) {
+        const int hp = (wave + CS_WAVES * k) * 8 + (lane >> 3);
+        const int hy = hp / CS_H, hx = hp - hy * CS_H;
+        const int flags = hp >= CS_H * CS_H ? 15 : ((hy == 0) | ((hy == CS_H - 1) << 1) | ((hx == 0) << 2) | ((hx == CS_H - 1) << 3));
+        lx_rel[k] = (((hy * p.S + hx) * p.in_cstride + (((lane & 7) ^ (hp & 7)) * 8)) * 2) | flags;
+    }
+    auto load_x = [&](int tile) {
+        const int n = tile / p.tiles_per_img, rem = tile - n * p.tiles_per_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int base = (((n * p.S + ty * CS_T - 1) * p.S + tx * CS_T - 1) * p.in_cstride + p.in_coff) * 2;
+        const int tmask = (ty == 0) | ((ty == p.tiles_x - 1) << 1) | ((tx == 0) << 2) | ((tx == p.tiles_x - 1) << 3);
+#pragma unroll
+        for (int k = 0; k < CS_NPIECE; ++k) {
+            const int u = wave + CS_WAVES * k;
+            if (u >= CS_HROWS / 8) break;                                  // wave-uniform
+            const int off = (lx_rel[k] & tmask) || (lx_rel[k] & 15) == 15 ? (int)0x80000000 : base + (lx_rel[k] & ~15);
+            buffer_load16_lds(rs_in, X1 + __builtin_amdgcn_readfirstlane(u * 1024), off, 0);
+        }
+    };
+#else
     auto load_x = [&](int tile) {
         const int n = tile / p.tiles_per_img, rem = tile - n * p.tiles_per_img;
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
@@ -142,33 +203,52 @@ __global__ __launch_bounds__(64 * CS_WAVES, 1) void csp_stage_kernel(const CspSt
             buffer_load16_lds(rs_in, X1 + __builtin_amdgcn_readfirstlane(u * 1024), ok ? off : (int)0x80000000, 0);
         }
     };
+#endif
     if (t < t_hi) load_x(t);
 
     // ---- per-wave fragment geometry (tile independent)
     // main fragments: inner rows iy = 2*wave + i -> halo'd row iy + 1, halo'd columns 1..16
     // extra fragment (waves 0..4): the halo ring -- row 0, row 17, and the two halo columns as 36 pixels in 3 fragments
-    int xr_main[2], xr_extra, ex_hy, ex_hx;
+    int xr_main[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) xr_main[i] = (2 * wave + i + 1) * CS_H + 1 + q;
-    {
-        if (wave < 2) { ex_hy = wave == 0 ? 0 : CS_H - 1; ex_hx = 1 + q; }
+    // ring fragment e = 0..4: 0 = halo row 0, 1 = halo row 17 (columns 1..16), 2..4 = the two halo columns (36 pixels, clamped)
+    auto ring_geom = [&](int e, int& hy, int& hx) {
+        if (e < 2) { hy = e == 0 ? 0 : CS_H - 1; hx = 1 + q; }
         else {
-            const int pp = min((wave - 2) * 16 + q, 2 * CS_H - 1);
-            ex_hy = pp >> 1; ex_hx = (pp & 1) * (CS_H - 1);
+            const int pp = min((e - 2) * 16 + q, 2 * CS_H - 1);
+            hy = pp >> 1; hx = (pp & 1) * (CS_H - 1);
         }
-        xr_extra = ex_hy * CS_H + ex_hx;
-    }
-    const bool has_extra = wave < 5;
+    };
+#if CS_EXTRA
+    // the older half of the workgroup (waves 0..3: they win every VALU arbitration on their SIMD) takes all five; wave 0 takes two
+    const int n_extra = wave == 0 ? 2 : wave < 4 ? 1 : 0;
+#else
+    const int n_extra = wave < 5 ? 1 : 0;
+#endif
 
+#if CS_PRIO == 2
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     bool first_tile = true;
+#ifdef CS_TRACE
+    int tr_i = 0;
+    unsigned long long tr_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (; t < t_hi; t += nb_x) {
         const int n = t / p.tiles_per_img, rem = t - n * p.tiles_per_img;
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+#ifdef CS_TRACE
+        const bool tr_on = blockIdx.x == CS_TR_WG && tr_i >= CS_TR_T0 && tr_i < CS_TR_T0 + 4;
+#endif
+        CS_POINT(0);                       // arrives at the tile barrier
         // X1 (and, the first time, the weights) have landed for every wave; every wave is done with the previous tile's
         // T4.  The previous tile's 4 output stores of this wave may still be in flight (they were issued after the DMA).
         if (first_tile) wait_vmcnt_then_barrier<0>();
         else wait_vmcnt_then_barrier<CS_VMCNT>();
         first_tile = false;
+        CS_POINT(1);                       // tile landed, barrier passed
+        CS_SEG(3);
 
         // ================= phase A: conv3 -> conv4 -> T4 on the halo'd tile; conv2 on the inner rows
         u32x4 C2[2][2], R3[2][2];              // route (conv2) and residual (conv3) of the wave's two inner fragments, packed
@@ -197,6 +277,7 @@ __global__ __launch_bounds__(64 * CS_WAVES, 1) void csp_stage_kernel(const CspSt
                         Mma<DT>::run(a2[i][j], w2[j], xf[i]);
                     }
             }
+            CS_POINT(2);                   // conv3 + conv2 MFMAs of the main fragments issued
 #pragma unroll
             for (int i = 0; i < 2; ++i) cs_act_pack<DT, 4>(a3[i], sc3, sh3, R3[i]);
             {
@@ -205,22 +286,8 @@ __global__ __launch_bounds__(64 * CS_WAVES, 1) void csp_stage_kernel(const CspSt
 #pragma unroll
                 for (int i = 0; i < 2; ++i) cs_act_pack<DT, 4>(a2[i], sc2, sh2, C2[i]);
             }
-            // conv3 of the halo-ring fragment
-            u32x4 X3e[2];
-            if (has_extra) {
-                f32x4 a3e[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a3e[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    u32x4 w3[4];
-                    const u32x4 xf = *(const u32x4*)(X1 + xr_extra * 128 + (((s * 4 + g) ^ (xr_extra & 7)) * 16));
-                    cs_wfrag<4>(smem + CS_W3, s, lane, w3);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) Mma<DT>::run(a3e[j], w3[j], xf);
-                }
-                cs_act_pack<DT, 4>(a3e, sc3, sh3, X3e);
-            }
+            CS_POINT(3);                   // their Mish
+            CS_SEG(2);
             // conv4 (64 -> 32) from registers, masked to zero outside the image, -> T4
             auto conv4_to_t4 = [&](const u32x4* x3, int xr, int hy, int hx) {
                 f32x4 a4[2];
@@ -238,13 +305,38 @@ __global__ __launch_bounds__(64 * CS_WAVES, 1) void csp_stage_kernel(const CspSt
                 if (!((unsigned)gy < (unsigned)p.S && (unsigned)gx < (unsigned)p.S)) pk = u32x4{0u, 0u, 0u, 0u};
                 *(u32x4*)(X4 + xr * 64 + ((g ^ ((xr >> 1) & 3)) * 16)) = pk;
             };
+            // conv3 -> conv4 of the halo-ring fragment(s)
+            for (int ex = 0; ex < n_extra; ++ex) {
+                int ex_hy, ex_hx;
+                ring_geom(CS_EXTRA && ex == 1 ? 4 : wave, ex_hy, ex_hx);
+                const int xr_extra = ex_hy * CS_H + ex_hx;
+                u32x4 X3e[2];
+                f32x4 a3e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a3e[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    u32x4 w3[4];
+                    const u32x4 xf = *(const u32x4*)(X1 + xr_extra * 128 + (((s * 4 + g) ^ (xr_extra & 7)) * 16));
+                    cs_wfrag<4>(smem + CS_W3, s, lane, w3);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Mma<DT>::run(a3e[j], w3[j], xf);
+                }
+                cs_act_pack<DT, 4>(a3e, sc3, sh3, X3e);
+                conv4_to_t4(X3e, xr_extra, ex_hy, ex_hx);
+            }
+            CS_POINT(4);                   // halo-ring conv3 -> conv4
+            CS_SEG(1);
 #pragma unroll
             for (int i = 0; i < 2; ++i) conv4_to_t4(R3[i], xr_main[i], 2 * wave + i + 1, 1 + q);
-            if (has_extra) conv4_to_t4(X3e, xr_extra, ex_hy, ex_hx);
         }
+        CS_POINT(5);                       // conv4 + Mish + T4 writes
         // T4 complete for every wave; X1 is free: start the next tile's DMA under phases C..E
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        CS_POINT(6);                       // mid barrier passed
+        CS_SEG(3);
         if (CS_ABL != 3 && t + nb_x < t_hi) load_x(t + nb_x);
+        CS_POINT(7);                       // next tile's DMA issued
 
         // ================= phase C: conv5 (3x3 over T4) + Add -> conv6 -> conv7 over [conv6 | route] -> HBM
         {
@@ -268,6 +360,7 @@ __global__ __launch_bounds__(64 * CS_WAVES, 1) void csp_stage_kernel(const CspSt
 #pragma unroll
                     for (int j = 0; j < 4; ++j) Mma<DT>::run(a5[i][j], w5[j], xf[i]);
             }
+            CS_POINT(8);                   // conv5 MFMAs issued
             u32x4 X5[2][2];
             {
                 float sc5[16], sh5[16];
@@ -289,6 +382,8 @@ __global__ __launch_bounds__(64 * CS_WAVES, 1) void csp_stage_kernel(const CspSt
                     for (int c = 0; c < 2; ++c) E::store_chunk(&X5[i][c], v + c * 8);
                 }
             }
+            CS_POINT(9);                   // conv5 Mish + Add
+            CS_SEG(2);
             // conv6: 64 -> 64 from registers
             u32x4 Y6[2][2];
             {
@@ -311,6 +406,8 @@ __global__ __launch_bounds__(64 * CS_WAVES, 1) void csp_stage_kernel(const CspSt
 #pragma unroll
                 for (int i = 0; i < 2; ++i) cs_act_pack<DT, 4>(a6[i], sc6, sh6, Y6[i]);
             }
+            CS_POINT(10);                  // conv6 + Mish
+            CS_SEG(1);
             // conv7: Concatenate([conv6, route]) (128) -> 64, then out
             {
                 f32x4 a7[2][4];
@@ -327,6 +424,7 @@ __global__ __launch_bounds__(64 * CS_WAVES, 1) void csp_stage_kernel(const CspSt
 #pragma unroll
                         for (int j = 0; j < 4; ++j) Mma<DT>::run(a7[i][j], w7[j], s < 2 ? Y6[i][s] : C2[i][s - 2]);
                 }
+                CS_POINT(11);              // conv7 MFMAs issued
                 float sc7[16], sh7[16];
                 cs_affine<2>(aff + CS_A7, 64, g, sc7, sh7);
 #pragma unroll
@@ -341,8 +439,24 @@ __global__ __launch_bounds__(64 * CS_WAVES, 1) void csp_stage_kernel(const CspSt
                 }
             }
         }
+        CS_POINT(12);                      // conv7 Mish + stores issued
+#ifdef CS_TRACE
+        if (tr_on && lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) cs_trace_buf[((tr_i - CS_TR_T0) * 8 + wave) * 16 + k] = tr_t[k];
+        }
+        ++tr_i;
+#endif
     }
 }
+
+#ifdef CS_TRACE
+}  // namespace y4
+extern "C" int y4_cs_trace_read(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(y4::cs_trace_buf), sizeof(unsigned long long) * 4 * 8 * 16);
+}
+namespace y4 {
+#endif
 
 // ------------------------------------------------------------------------------------------------ launch
 bool csp_stage_supported(int dtype, int side) { return dtype != Y4_F32 && side % CS_T == 0 && side >= CS_T; }

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
     // the blob (affine tables + both convs' weight streams: every tile streams all of it) -> this XCD's L2, shared out over the
     // workgroups (conv_common.h: weight_touch); the dwords land in the wave's piece of ring slot 0, which its stage_w(0) overwrites
+    static_assert(G::PPW >= 1, "every wave must own piece `wave` of ring slot 0 (stage_w(0), k = 0): it is the touch scratch");
     if (p.touch != 0) weight_touch(rb, ring + __builtin_amdgcn_readfirstlane(wave * 1024), 0, G::BLOB_BYTES, wave, RB_WAVES, lane);
     // affine -> LDS once per workgroup
     for (int u = wave; u < G::AFF_PAD / 1024; u += RB_WAVES)

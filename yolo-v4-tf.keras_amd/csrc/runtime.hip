@@ -933,6 +933,37 @@ static int forward_impl(y4_handle h, const void* imgs, bool u8, int n, void* str
     return rc;
 }
 
+// The forward pass up to and including conv `last_conv` (bench.py's backbone-only mode: last_conv = 71 is CSPDarknet53 proper,
+// reference custom_layers.py:100-124).  The conv must end a launch: a run / residual-block kernel that is in force and continues
+// past it is refused instead of being cut.
+int y4_forward_until(y4_handle h, const float* imgs, int n, int last_conv, void* stream) {
+    if (int r = check_ready(h, n)) return r;
+    Y4_REQUIRE(imgs, Y4_EINVAL, "y4_forward_until: null images");
+    int last_op = -1;
+    for (int i = 0; i < (int)h->ops.size(); ++i)
+        if (h->ops[i].kind != OP_SPP && (h->ops[i].conv == last_conv || h->ops[i].conv2 == last_conv)) last_op = i;
+    Y4_REQUIRE(last_op >= 0, Y4_EINVAL, "y4_forward_until: no conv %d", last_conv);
+    if (h->fuse_chains)
+        for (const Chain& ch : h->chains)
+            Y4_REQUIRE(!(h->chain_active(ch) && ch.head <= last_op && (ch.tail[0] > last_op || ch.tail[1] > last_op)), Y4_EINVAL,
+                       "y4_forward_until: conv %d sits inside a fused run that continues behind it", last_conv);
+    {
+        bool is_head = false;
+        Y4_REQUIRE(!(h->res_of(last_op, &is_head) && is_head), Y4_EINVAL,
+                   "y4_forward_until: conv %d heads a residual-block kernel that continues behind it", last_conv);
+    }
+    Y4_REQUIRE(!(h->stage_active() && last_op >= h->stage_first && last_op < h->stage_last), Y4_EINVAL,
+               "y4_forward_until: conv %d sits inside the stage kernel", last_conv);
+    Y4_REQUIRE(!(h->fuse_stem && last_op == 0), Y4_EINVAL, "y4_forward_until: conv 0 runs fused with conv 1");
+    h->img_u8 = false;
+    std::vector<Launch> sched;
+    build_schedule(h, n, sched);
+    int rc = Y4_OK;
+    for (const Launch& l : sched)
+        if (l.op <= last_op && (rc = run_op(h, h->ops[l.op], imgs, l.cnt, (hipStream_t)stream, l.img0))) break;
+    return rc;
+}
+
 int y4_forward(y4_handle h, const float* imgs, int n, void* stream) { return forward_impl(h, imgs, false, n, stream); }
 int y4_forward_u8(y4_handle h, const uint8_t* imgs, int n, void* stream) { return forward_impl(h, imgs, true, n, stream); }
 
@@ -1190,7 +1221,9 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
                 return t_end(&ms) ? ms : -2.f;
             };
             float t_fused = 0.f, t_sep = 0.f;
-            bool fused_ok = block(true) >= 0.f, sep_ok = block(false) >= 0.f;   // one untimed block each: both start equally warm
+            const float w_f = block(true), w_s = block(false);                 // one untimed block each: both start equally warm
+            if (w_f == -2.f || w_s == -2.f) { rc = Y4_EHIP; break; }           // (an event failure is not "fused lost")
+            bool fused_ok = w_f >= 0.f, sep_ok = w_s >= 0.f;
             for (int r = 0; r < rounds && rc == Y4_OK && fused_ok && sep_ok; ++r) {
                 const float a = block(true), b = block(false);
                 if (a == -2.f || b == -2.f) { rc = Y4_EHIP; break; }
@@ -1219,7 +1252,9 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
             return t_end(&ms) ? ms : -2.f;
         };
         float t_fused = 0.f, t_sep = 0.f;
-        bool fused_ok = block(true) >= 0.f, sep_ok = block(false) >= 0.f;
+        const float w_f = block(true), w_s = block(false);
+        if (w_f == -2.f || w_s == -2.f) rc = Y4_EHIP;
+        bool fused_ok = w_f >= 0.f, sep_ok = w_s >= 0.f;
         for (int r = 0; r < rounds && rc == Y4_OK && fused_ok && sep_ok; ++r) {
             const float a = block(true), b = block(false);
             if (a == -2.f || b == -2.f) { rc = Y4_EHIP; break; }
@@ -1252,7 +1287,9 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
             return t_end(&ms) ? ms : -2.f;
         };
         float t_fused = 0.f, t_sep = 0.f;
-        bool fused_ok = block(true) >= 0.f, sep_ok = block(false) >= 0.f;
+        const float w_f = block(true), w_s = block(false);
+        if (w_f == -2.f || w_s == -2.f) rc = Y4_EHIP;
+        bool fused_ok = w_f >= 0.f, sep_ok = w_s >= 0.f;
         for (int r = 0; r < rounds && rc == Y4_OK && fused_ok && sep_ok; ++r) {
             const float a = block(true), b = block(false);
             if (a == -2.f || b == -2.f) { rc = Y4_EHIP; break; }
@@ -1275,6 +1312,13 @@ int y4_autotune(y4_handle h, int n, int reps, void* stream) { return autotune_im
 int y4_autotune_pair(y4_handle h, y4_handle h2, int n, int reps, void* stream, void* stream2, int pair_passes) {
     if (int r = check_handle(h2)) return r;
     Y4_REQUIRE(pair_passes >= 0 && pair_passes <= 15, Y4_EINVAL, "y4_autotune_pair: pair_passes %d (bits 0..3)", pair_passes);
+    if (int r = check_handle(h)) return r;
+    // the sibling is tuned with the primary's choices: they only apply to it if it runs the same kernels
+    Y4_REQUIRE(h2->fuse_stem == h->fuse_stem && h2->fuse_chains == h->fuse_chains && h2->stage_on == h->stage_on &&
+               h2->res_on == h->res_on && h2->sub_images == h->sub_images && h2->sub_last_op == h->sub_last_op &&
+               h2->alias_bufs == h->alias_bufs, Y4_ESTATE,
+               "y4_autotune_pair: the two handles differ in their fusion switches, sub-batching or workspace aliasing "
+               "(y4_copy_schedule(h, h2) makes them equal)");
     return autotune_impl(h, h2, n, reps, (hipStream_t)stream, (hipStream_t)stream2, pair_passes);
 }
 
@@ -1288,12 +1332,14 @@ int y4_set_tiles(y4_handle h, const int32_t* tiles, int count) {
         Chain* head_of = nullptr;
         for (Chain& ch : h->chains)
             if (ch.head == oi) head_of = &ch;
-        Y4_REQUIRE(v <= conv_tile_count() && -v <= conv_tile_count() && (v >= 0 || (head_of && h->fuse_chains)), Y4_EINVAL,
+        // a run's head carries two choices in one entry: -(run tile + 1000 * stand-alone tile); plain -t leaves the stand-alone one
+        const int run_tile = v < 0 ? (-v) % 1000 : 0, own_tile = v < 0 ? (-v) / 1000 : v;
+        Y4_REQUIRE(own_tile <= conv_tile_count() && run_tile <= conv_tile_count() && (v >= 0 || (head_of && h->fuse_chains)), Y4_EINVAL,
                    "y4_set_tiles: tile id %d for conv %d", v, op.conv);
-        if (head_of && h->fuse_chains) {      // < 0: chained with tile -v; > 0: separate kernels; 0: chained, heuristic tile
+        if (head_of && h->fuse_chains) {      // < 0: chained with tile run_tile; > 0: separate kernels; 0: chained, heuristic tile
             head_of->enabled = v <= 0;
-            head_of->tile = v < 0 ? -v : 0;
-            if (v > 0) op.tile = v;
+            head_of->tile = run_tile;
+            if (v > 0 || own_tile > 0) op.tile = own_tile;
         } else {
             op.tile = v;
         }
@@ -1391,9 +1437,35 @@ int y4_get_tiles(y4_handle h, int32_t* tiles, int cap) {
             tiles[op.conv] = op.tile;
             if (op.conv2 >= 0) tiles[op.conv2] = op.tile;
         }
-    if (h->fuse_chains)                       // a chained run reports its head as -tile (see y4_set_tiles)
-        for (const Chain& ch : h->chains)
-            if (ch.enabled) tiles[h->ops[ch.head].conv] = -ch.tile;
+    if (h->fuse_chains)                       // a chained run reports its head as -(run tile + 1000 * the conv's stand-alone tile), so
+        for (const Chain& ch : h->chains)     // that a get -> set round trip loses neither (see y4_set_tiles)
+            if (ch.enabled) tiles[h->ops[ch.head].conv] = -(ch.tile + 1000 * h->ops[ch.head].tile);
+    return Y4_OK;
+}
+
+// Every scheduling choice of `src` -> `dst` (a sibling built from the same configuration): the per-op tiles, every run's
+// enabled / tile state INCLUDING the stand-alone tile of a conv that currently heads a run (y4_get_tiles reports such a conv as
+// -run_tile and cannot carry both), the stage-kernel and residual-block verdicts, the fusion switches and sub-batching.
+int y4_copy_schedule(y4_handle src, y4_handle dst) {
+    if (int r = check_handle(src)) return r;
+    if (int r = check_handle(dst)) return r;
+    Y4_REQUIRE(src != dst, Y4_EINVAL, "y4_copy_schedule: source and destination are the same handle");
+    Y4_REQUIRE(dst->t_max_steps == 0, Y4_ESTATE, "y4_copy_schedule: a timing session is open on the destination");
+    Y4_REQUIRE(src->ops.size() == dst->ops.size() && src->chains.size() == dst->chains.size() &&
+               src->resruns.size() == dst->resruns.size() && src->cfg.dtype == dst->cfg.dtype && src->S == dst->S &&
+               src->cfg.num_classes == dst->cfg.num_classes && src->cfg.max_batch == dst->cfg.max_batch, Y4_EINVAL,
+               "y4_copy_schedule: the handles were not created from the same configuration");
+    Y4_REQUIRE(src->sub_images <= 0 || !dst->alias_bufs, Y4_ESTATE,
+               "y4_copy_schedule: the source runs sub-batches, the destination's workspace is aliased");
+    for (size_t i = 0; i < src->ops.size(); ++i) dst->ops[i].tile = src->ops[i].tile;
+    for (size_t i = 0; i < src->chains.size(); ++i) {
+        dst->chains[i].enabled = src->chains[i].enabled;
+        dst->chains[i].tile = src->chains[i].tile;
+    }
+    dst->fuse_stem = src->fuse_stem; dst->fuse_chains = src->fuse_chains;
+    dst->stage_on = src->stage_on; dst->stage_enabled = src->stage_enabled;
+    dst->res_on = src->res_on; dst->res_enabled[0] = src->res_enabled[0]; dst->res_enabled[1] = src->res_enabled[1];
+    dst->sub_images = src->sub_images; dst->sub_last_op = src->sub_last_op;
     return Y4_OK;
 }
 

@@ -39,6 +39,22 @@ constexpr int SD_UNROLL = 4;                            // stem tiles whose gath
 
 static __device__ __forceinline__ int sd_swz(int row) { return (row >> 1) & 3; }
 
+#ifdef SD_TRACE
+// In-kernel phase trace (kernel experiments only; scripts/stem_trace.py): workgroup SD_TR_WG records s_memtime per wave at fixed
+// points of its output rows SD_TR_R0 .. +3 into sd_trace_buf[row][wave][point]; y4_sd_trace_read() copies it out.
+__device__ unsigned long long sd_trace_buf[4 * 16 * 8];
+#define SD_TR_WG 8
+#define SD_TR_R0 5
+#define SD_POINT(P)                                                                                         \
+    do {                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (tr_on) asm volatile("s_memtime %0" : "=s"(tr_t[P]));                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    } while (0)
+#else
+#define SD_POINT(P)
+#endif
+
 template <int DT, int MFW, class IMG>     // MFW = max pixel fragments per wave row: ceil((Wo/16) / SD_WM)
 __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDownK p) {
     using E = Elem<DT>;
@@ -89,8 +105,15 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
         for (int e = 0; e < 4; ++e) { sc1[c + e] = s4[e]; sh1[c + e] = h4[e]; }
     }
 
+#ifdef SD_TRACE
+    unsigned long long tr_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int orow_i = r_begin; orow_i < r_end; ++orow_i) {
     const int n = orow_i / Wo, ho = orow_i - n * Wo;
+#ifdef SD_TRACE
+    const bool tr_on = blockIdx.x == SD_TR_WG && orow_i - r_begin >= SD_TR_R0 && orow_i - r_begin < SD_TR_R0 + 4;
+#endif
+    SD_POINT(0);                          // row start
     // c0 rows 2ho-1+ry, ry = ry_first .. 2, are new; row 2ho-1 is the previous output row's 2(ho-1)+1, still in its slot
     const int ry_first = (orow_i == r_begin || ho == 0) ? 0 : 1;
     // ---- 2. c0 rows -> LDS ring (MFMA stem: stem_mfma_kernel's arithmetic, stem_common.h's K layout)
@@ -127,11 +150,8 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
             };
             auto bn_act_pack = [&](const f32x4& a0, const f32x4& a1) {
                 float o[8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    o[r] = apply_act_t<true, Y4_ACT_LEAKY>(fmaf(a0[r], sc[r], sh[r]));
-                    o[4 + r] = apply_act_t<true, Y4_ACT_LEAKY>(fmaf(a1[r], sc[4 + r], sh[4 + r]));
-                }
+                bn_act4<true, Y4_ACT_LEAKY>(a0, sc, sh, o);              // packed BN + 0.1x, per-element max: same bits as the scalar form
+                bn_act4<true, Y4_ACT_LEAKY>(a1, sc + 4, sh + 4, o + 4);
                 u32x4 packed;
                 E::store_chunk(&packed, o);
                 return packed;
@@ -194,8 +214,10 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
             }
         }
     }
+    SD_POINT(1);                          // stem tiles done (strip stores issued)
     if (orow_i == r_begin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the c1 weights (staged once)
     __syncthreads();
+    SD_POINT(2);                          // barrier passed
 
     // ---- L2 prefetch of the image rows the NEXT output row's stem will read for the first time (two rows, contiguous
     //      in memory; three at an image's first row): one LDS-DMA load per wave into a scratch KB -- no registers, nobody
@@ -235,6 +257,7 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
         }
     }
 
+    SD_POINT(3);                          // conv 1 MFMAs issued
     // ---- 4. BN + activation; the lane holds channels g*16 + wn*8 + (0..7) of its pixel -> one 16-byte store
     const float* sc = sc1; const float* sh = sh1;
     T* const orow = (T*)p.out + ((int64_t)(n * Wo + ho) * Wo) * p.out_cstride + p.out_coff + g * 16 + wn * 8;
@@ -244,17 +267,31 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
         if (frag < MF) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[j * 4 + r] = apply_act_t<true, Y4_ACT_LEAKY>(fmaf(acc[f][j][r], sc[j * 4 + r], sh[j * 4 + r]));
+            for (int j = 0; j < 2; ++j) bn_act4<true, Y4_ACT_LEAKY>(acc[f][j], sc + j * 4, sh + j * 4, v + j * 4);
             u32x4 pk;
             E::store_chunk(&pk, v);
             *(u32x4*)(orow + (int64_t)(frag * 16 + q) * p.out_cstride) = pk;
         }
     }
+    SD_POINT(4);                          // epilogue done, stores issued
     __syncthreads();                  // every wave has read the ring: the next row's stem may overwrite two of its slots
+    SD_POINT(5);                          // second barrier passed
+#ifdef SD_TRACE
+    if (tr_on && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sd_trace_buf[((orow_i - r_begin - SD_TR_R0) * 16 + wave) * 8 + k] = tr_t[k];
+    }
+#endif
     }                                 // output rows of the band
 }
+
+#ifdef SD_TRACE
+}  // namespace y4
+extern "C" int y4_sd_trace_read(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(y4::sd_trace_buf), sizeof(unsigned long long) * 4 * 16 * 8);
+}
+namespace y4 {
+#endif
 
 // c1 weights + c0 ring + the prefetch's scratch KB
 size_t stem_down_lds_bytes(int S) { return (size_t)9 * 64 * 64 + (size_t)3 * 2 * (S / 2 + 1) * 64 + 1024; }

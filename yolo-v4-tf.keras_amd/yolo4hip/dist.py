@@ -123,6 +123,17 @@ def max_over_ranks(value):
     return vals if many else vals[0]
 
 
+def gather_objects(obj):
+    """[rank 0's obj, rank 1's, ...] on every rank (a small python object per rank: a timing, a device name); [obj] without a
+    process group.  Host-side pickling -- never inside a timed region."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

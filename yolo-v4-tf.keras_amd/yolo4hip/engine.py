@@ -99,20 +99,12 @@ class Engine:
         return e
 
     def copy_schedule_to(self, e):
-        """Give engine `e` (a sibling) this engine's scheduling choices: sub-batching, fusions, tuned tiles."""
-        sub = getattr(self, "_subbatch", None)
-        e.set_subbatch(*(sub or (0, 16)))
-        if self.dtype != "f32":
-            e.set_stem_fusion(bool(getattr(self, "stem_fusion", False)))
-            e.set_chain_fusion(bool(getattr(self, "chain_fusion", False)))
-            e.set_stage_fusion(self.stage_fusion_active())
-            mask = self.res_fusion_mask()
-            e.set_res_fusion(bool(mask))
-            if mask:
-                e.set_res_fusion_mask(mask)
-        tiles = (C.c_int32 * 110)()
-        ext.check(self.lib.y4_get_tiles(self.handle, tiles, 110))
-        e.set_tiles(list(tiles))
+        """Give engine `e` (a sibling) this engine's scheduling choices: sub-batching, fusions, every run's state, tuned tiles
+        (y4_copy_schedule mirrors the handle itself; a get_tiles -> set_tiles hop could not carry a run head's two tiles)."""
+        ext.check(self.lib.y4_copy_schedule(self.handle, e.handle))
+        e._subbatch = getattr(self, "_subbatch", None)
+        e.stem_fusion = bool(getattr(self, "stem_fusion", False))
+        e.chain_fusion = bool(getattr(self, "chain_fusion", False))
 
     def close(self):
         for e in getattr(self, "_stream_siblings", []):
@@ -261,6 +253,15 @@ class Engine:
             fn = self.lib.y4_forward_u8 if u8 else self.lib.y4_forward
             ext.check(fn(self.handle, ext.ptr(imgs_dev), n, ext.stream_ptr()))
 
+    def forward_until_device(self, imgs_dev, last_conv=71):
+        """The forward pass cut behind conv `last_conv` (default 71: CSPDarknet53 proper, reference custom_layers.py:100-124) on a
+        float32 device batch -- what `bench.py` times as `backbone`.  Asynchronous on the current stream."""
+        n = imgs_dev.shape[0]
+        if self._check_device_images(imgs_dev):
+            raise ValueError("forward_until_device takes float32 images")
+        with self.torch.cuda.device(self.device):
+            ext.check(self.lib.y4_forward_until(self.handle, ext.ptr(imgs_dev), n, int(last_conv), ext.stream_ptr()))
+
     def heads_device(self, n):
         torch = self.torch
         outs = [torch.empty((n, g, g, self.nout), dtype=torch.float32, device=self.device) for g in self.grids]
@@ -351,7 +352,7 @@ class Engine:
         res = [np.concatenate(p, axis=0) for p in acc]
         return res if with_indices else res[:4]
 
-    def predict_stream(self, batches, with_indices=False, in_flight=2):
+    def predict_stream(self, batches, with_indices=False, in_flight=None):
         """Pipelined `inference_model.predict` over an iterable of uint8 batches ([n,h,w,3] numpy arrays or pinned torch
         tensors, n <= max_batch, any h,w): yields one result list per batch, in order.  A pinned tensor is uploaded from where
         it lies and may be refilled as soon as the generator yields (its upload is waited for before every yield).  While batch i computes, batch i+1 crosses PCIe as uint8
@@ -359,13 +360,17 @@ class Engine:
         host, so the PCIe-inclusive rate approaches the device rate.  No float image tensor exists: frames are resized
         uint8 -> uint8 on the device when needed (`y4_resize_u8`) and the `/ 255.` happens inside the stem's operand load
         (`y4_predict_u8`), bit-identical to `Yolov4.preprocess_img` (reference models.py:95-98) + float32 forward.
-        `in_flight` (default 2) batches compute at the same time, each on its own HIP stream and activation workspace
-        (`sibling()`: shared packed weights), so that one batch's idle compute units are the other's (see `InFlight`);
-        results are unchanged and still come in order."""
+        `in_flight` batches compute at the same time, each on its own HIP stream and activation workspace (`sibling()`: shared
+        packed weights), so that one batch's idle compute units are the other's (see `InFlight`); results are unchanged and still
+        come in order.  Every batch in flight beyond the first costs one more activation workspace for the engine's lifetime
+        (`act_bytes`: 2.9 GB at 608x608 / batch 32 / bf16 with `alias_workspace`, 8.0 GB without), so the default is 2 with an
+        aliased workspace and 1 with the plain one; pass `in_flight` to choose."""
         torch = self.torch
         dev = self.device
         copy_stream = torch.cuda.Stream(device=dev)        # uploads
         down_stream = torch.cuda.Stream(device=dev)        # results (its own stream: it waits for the compute stream)
+        if in_flight is None:
+            in_flight = 2 if self.alias_workspace else 1
         in_flight = max(1, int(in_flight))
         sibs = getattr(self, "_stream_siblings", [])
         while len(sibs) < in_flight - 1:
@@ -379,6 +384,10 @@ class Engine:
         # costs milliseconds, which a short stream would pay again on every call
         cache = getattr(self, "_stream_slots", None)
         if cache is None or len(cache) != nslots:
+            for sl in cache or []:                         # an abandoned generator may have left copies in flight on these buffers
+                for ev in ("up", "ran", "done"):
+                    if ev in sl:
+                        sl[ev].synchronize()
             cache = self._stream_slots = [{} for _ in range(nslots)]
         slots = cache
         for sl in slots:

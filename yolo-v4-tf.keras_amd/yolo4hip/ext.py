@@ -65,6 +65,7 @@ SYMBOLS = {
     "y4_adopt_packed_weights": (_I, [_VP]),
     "y4_forward": (_I, [_VP, _VP, _I, _VP]),
     "y4_forward_u8": (_I, [_VP, _VP, _I, _VP]),
+    "y4_forward_until": (_I, [_VP, _VP, _I, _I, _VP]),
     "y4_get_heads": (_I, [_VP, _I, _VP, _VP, _VP, _VP]),
     "y4_set_heads": (_I, [_VP, _I, _VP, _VP, _VP, _VP]),
     "y4_get_conv_output": (_I, [_VP, _I, _I, _VP, C.c_size_t, _VP]),
@@ -77,6 +78,7 @@ SYMBOLS = {
     "y4_autotune_pair": (_I, [_VP, _VP, _I, _I, _VP, _VP, _I]),
     "y4_get_tiles": (_I, [_VP, C.POINTER(C.c_int32), _I]),
     "y4_set_tiles": (_I, [_VP, C.POINTER(C.c_int32), _I]),
+    "y4_copy_schedule": (_I, [_VP, _VP]),
     "y4_set_subbatch": (_I, [_VP, _I, _I]),
     "y4_set_stem_fusion": (_I, [_VP, _I]),
     "y4_set_chain_fusion": (_I, [_VP, _I]),
