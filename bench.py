@@ -94,6 +94,64 @@ def cpu_baseline(size, ncls, ws, cfg, batch=32, runs=3):
                       f"this host and collapses at all {hw_threads})"}
 
 
+def latency_block(classes, flat, class_file, img_path, iters=200):
+    """The reference's actual call is ONE image -- `Yolov4.predict(img_path)` (models.py:109-127; BASELINE configs 1 and 2): wall
+    time of one `y4_predict` + the copy of its results to the host, synchronised per call, median (p50) and p90 of `iters` calls,
+    at 608 and 416, bf16 and fp32, each on the latency schedule that ships for it (split-K ids allowed: engine.ensure_schedule),
+    and of the facade's `predict` on img/street.jpeg (imread + device resize + predict + DataFrame).  A latency, not `value`."""
+    import numpy as np
+    import torch
+    from yolo4hip import weights as W
+    from yolo4hip.config import make_config
+    from yolo4hip.engine import Engine
+    from yolo4hip.plan import build_plan
+    out = {"what": "p50 / p90 wall ms of one synchronised y4_predict of ONE image incl. its results' copy to the host",
+           "iters": iters}
+    for size in (608, 416):
+        plan = build_plan(size, classes)
+        for dtype in ("bf16", "f32"):
+            eng = Engine(classes, make_config(size), max_batch=1, dtype=dtype, alias_workspace=True)
+            eng.load_weight_blob(flat)
+            src, path = eng.ensure_schedule(tune=True, verbose=False)
+            imgs = torch.from_numpy(W.synth_images(1, size, seed=0)).to(eng.device)
+            fl, outs = eng.alloc_outputs_flat(1)
+            host = torch.empty(fl.numel(), dtype=torch.int32).pin_memory()
+            ts = []
+            for i in range(iters + 20):
+                t0 = time.perf_counter()
+                eng.predict_device(imgs, outs)
+                host.copy_(fl, non_blocking=True)
+                torch.cuda.synchronize()
+                if i >= 20:
+                    ts.append(time.perf_counter() - t0)
+            ts.sort()
+            p50 = ts[len(ts) // 2] * 1e3
+            out[f"{size}_{classes}_b1_{dtype}"] = {
+                "p50_ms": round(p50, 4), "p90_ms": round(ts[int(len(ts) * 0.9)] * 1e3, 4),
+                "frac_of_mfma_peak": round(plan.flops_per_image / (p50 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[dtype], 4),
+                "schedule": src + (": " + os.path.basename(path) if path else "")}
+            eng.close()
+    try:
+        from yolo4hip.api import Yolov4
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = Yolov4(None, class_file, make_config(416), dtype="bf16", max_batch=1)
+            m.predict(img_path, plot_img=False)
+            ts = []
+            for _ in range(20):
+                t0 = time.perf_counter()
+                m.predict(img_path, plot_img=False)
+                ts.append(time.perf_counter() - t0)
+        ts.sort()
+        out["facade_predict_street_jpeg_416_bf16"] = {"p50_ms": round(ts[len(ts) // 2] * 1e3, 3),
+                                                      "what": "Yolov4.predict(img/street.jpeg): imread + uint8 upload + device resize + "
+                                                              "y4_predict_u8 + get_detection_data (DataFrame) + draw_bbox, host wall time"}
+        m.engine.close()
+    except Exception as e:                                    # PIL / pandas missing on some host: the engine numbers stand
+        out["facade_predict_street_jpeg_416_bf16"] = {"error": repr(e)}
+    return out
+
+
 def committed_traffic(args, fused_stem, chained, staged, res_mask, tiles):
     """HBM bytes per STEP of the conv kernel family from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes), or (None, reason) when this
@@ -157,6 +215,8 @@ def parse_args(argv):
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the `latency` block (one-image y4_predict at 608 / 416, bf16 / fp32, and the facade's predict)")
     ap.add_argument("--cpu-batch", type=int, default=32,
                     help="batch of the CPU proxy baseline (SURVEY.md 8(d): 32 and 1; 1 warm-up + 3 timed runs each, ~55 s of host time)")
     ap.add_argument("--stop-after-conv", type=int, default=71,
@@ -523,6 +583,10 @@ def main():
             for name, ms in ops:
                 fl = sum(plan.convs[int(i)].flops_per_image for i in name[1:].split("+")) * (hi - lo) if name.startswith("c") else 0
                 print(f"{name:8s} {ms:8.4f} ms  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.1f} TFLOP/s", file=sys.stderr)
+        if world == 1 and not args.no_latency and args.classes == 80:
+            pkg = os.path.join(ROOT, "yolo-v4-tf.keras_amd")
+            line["latency"] = latency_block(args.classes, W.flatten(ws_holder.get("ws") or W.synth_weights(plan, seed=0)),
+                                            os.path.join(pkg, "class_names", "coco_classes.txt"), os.path.join(pkg, "img", "street.jpeg"))
         if world == 1 and not args.no_cpu_baseline:
             ws = ws_holder.get("ws") or W.synth_weights(plan, seed=0)
             line["cpu_baseline"] = cpu_baseline(args.size, args.classes, ws, cfg, batch=args.cpu_batch)

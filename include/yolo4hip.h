@@ -253,6 +253,11 @@ typedef struct y4_conv_desc {
      * Used to run a CSP block's route conv and main-in conv (same input, custom_layers.py:58-60) as ONE GEMM. */
     void* out2;
     int32_t out2_cstride, out2_coff, split;
+    /* split-K (tile = base + 100 e: the base tile's K loop split 2^e ways, e = 1..3; for launches with fewer tiles than compute
+     * units): device scratch of 16 KiB of tile counters, ZERO before the first use (every launch leaves them zero), followed by
+     * 2^e x tiles x BM x BN floats of partial sums.  NULL / 0 when no split tile is used. */
+    void* splitk_ws;
+    size_t splitk_ws_bytes;
 } y4_conv_desc;
 
 /* cout_pad (rows of the packed matrix) and bytes needed for a packed kernel */
@@ -268,6 +273,12 @@ int y4_conv_tile_count(void);
  * channels, bytes of K per LDS row, schedule code (2..4 = ring stages, 12 = staggered 2-stage, 32 = 2-stage with the 32x32x16
  * MFMA)}.  All tiles with the 16x16x32 MFMA give bit-identical results; the 32x32x16 tiles agree among themselves. */
 int y4_conv_tile_desc(int tile, int32_t cfg[6]);
+/* Latency schedules (the reference's own call is one image: Yolov4.predict, models.py:109-127).  With few images the deep layers
+ * have fewer output tiles than the GPU has compute units and each tile walks a long K loop alone; `on` lets y4_autotune also offer
+ * split-K tile ids (base + 100 e: the K loop of a tile split over 2^e workgroups, the last one to finish adds the partial sums in
+ * split order and runs the epilogue).  A split launch sums in another fp32 order than the unsplit one, so with this switch the
+ * tuned schedule is part of the numerical result (like the 32x32x16 tiles; tested against the oracle); off by default. */
+int y4_set_splitk(y4_handle h, int on);
 /* Stem conv (cin = 3, reference custom_layers.py:101): float32 images -> dtype.  `wk_dev` is an 8192-byte table
  * made by y4_pack_stem_weights from Darknet (cout,3,3,3) order: float32 [(ky*3+kx)*3+ci][cout] for the fp32
  * kernel, then (byte 4096 / 6144) the bf16 / fp16 MFMA weight fragments used by the 16-bit kernels. */

@@ -72,7 +72,18 @@ def run_conv_gpu(x, cw, k, stride, act, dtype, residual=None, upsample=False, ou
     if residual is not None:
         res_t = torch.from_numpy(residual).to(dev).to(td).contiguous()
         d.res = res_t.data_ptr(); d.res_cstride = residual.shape[-1]; d.res_coff = 0
+    ws = None
+    if tile >= 100:                      # split-K tile id: counters (zero before the first use) + partial sums
+        ws = torch.zeros(16 * 1024 + 32 * 1024 * 1024, dtype=torch.uint8, device=dev)
+        d.splitk_ws = ws.data_ptr(); d.splitk_ws_bytes = ws.numel()
     ext.check(lib.y4_conv2d(C.byref(d), ext.stream_ptr()))
+    if ws is not None:                   # a second launch on the same scratch: the counters were left at zero
+        first = out.clone()
+        out.fill_(-5.0)
+        ext.check(lib.y4_conv2d(C.byref(d), ext.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(first, out), "a split-K launch is not repeatable on its own scratch"
+        assert int(ws[:16 * 1024].view(torch.int32).abs().sum()) == 0, "split-K tile counters not back at zero"
     torch.cuda.synchronize()
     full = out.float().cpu().numpy()
     return full[..., out_pad[0]:out_pad[0] + cout], full
@@ -125,3 +136,18 @@ def detection_agreement(kept, classes, scores, boxes, valid, ri, rc, rs, rb, rv)
     ds = max((abs(float(scores[got[k]]) - float(rs[ref[k]])) for k in common), default=0.0)
     db = max((float(np.abs(boxes[got[k]] - rb[ref[k]]).max()) for k in common), default=0.0)
     return (len(common) / max(len(ref), 1)), ds, db
+
+
+def shift_objectness(ws, num_classes, delta):
+    """A copy of a weight set whose three head convs (93, 101, 109: bias, no BN; custom_layers.py:141-198) have `delta` added to
+    the bias of their objectness channels (channel 4 of each anchor's 5 + C block): with delta < 0 fewer boxes pass the score
+    threshold -- the `valid < 100` regime of CombinedNMS (tests/golden/make_ref_sparse_fixture.py)."""
+    from yolo4hip.weights import ConvWeights
+    out = list(ws)
+    for idx in (93, 101, 109):
+        cw = out[idx]
+        assert cw.bias is not None and cw.bias.shape[0] == 3 * (5 + num_classes), (idx, None if cw.bias is None else cw.bias.shape)
+        b = cw.bias.copy()
+        b[4::5 + num_classes] += np.float32(delta)
+        out[idx] = ConvWeights(w=cw.w, bn=cw.bn, bias=b)
+    return out

@@ -141,6 +141,52 @@ def test_mfma32_tiles_vs_oracle(dtype):
     assert ran >= 6
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_splitk_tiles_vs_oracle(dtype):
+    """Split-K tile ids (base + 100 e: the K loop split 2^e ways, the last split to arrive adds the partial sums and runs the
+    epilogue; the latency schedules of batch 1) against the same float64-free reference and tolerance as every other tile --
+    they sum in another fp32 order, so they are held to the oracle, not to bit-identity: the deep 19^2 3x3 shapes, a strided one
+    with a residual, a 1x1 head with Cout = 255 and float32 output, a ragged pixel count; every launch is repeated on its scratch
+    (run_conv_gpu) to prove the tile counters return to zero.  Ids that cannot split (too few K-tiles, fused tiles) are refused."""
+    import ctypes as C
+    from yolo4hip import ext
+    from yolo4hip.weights import ConvWeights
+    lib = ext.load()
+    atol, rtol = TOL[dtype]
+    bases = [8, 10, 12, 16, 3] if dtype != "f32" else [8, 10, 3]
+    ran = 0
+    for (k, stride, cin, cout, side, act, use_res, out_f32) in [(3, 1, 512, 1024, 19, "leaky", False, False),
+                                                                 (3, 2, 256, 512, 38, "mish", False, False),
+                                                                 (3, 1, 256, 256, 19, "mish", True, False),
+                                                                 (1, 1, 1024, 255, 19, "linear", False, True),
+                                                                 (1, 1, 512, 256, 13, "leaky", False, False)]:
+        rng = np.random.default_rng(cin + cout + k)
+        x = quantize(rng.standard_normal((1, side, side, cin)).astype(np.float32), dtype)
+        cw = make_conv_weights(rng, cout, cin, k, act != "linear")
+        cwq = ConvWeights(w=quantize(cw.w, dtype), bn=cw.bn, bias=cw.bias)
+        so = side // stride
+        res = quantize(rng.standard_normal((1, so, so, cout)).astype(np.float32), dtype) if use_res else None
+        want = _ref(x, cwq, k, stride, act, res, False)
+        for base in bases:
+            for e in (1, 2, 3):
+                try:
+                    got, _ = run_conv_gpu(x, cwq, k, stride, act, dtype, residual=res, out_f32=out_f32, tile=base + 100 * e)
+                except ext.Y4Error as err:
+                    assert err.code == -22
+                    continue
+                d = np.abs(got - want)
+                assert np.all(d <= atol + rtol * np.abs(want)), f"tile {base}+{100 * e} {k}x{k} {cin}->{cout}: max err {d.max():.3e}"
+                ran += 1
+    assert ran >= 30, ran
+    # refused: a split of a fused / phased tile id, a 16-way split, a split wider than the K-tiles allow
+    rng = np.random.default_rng(1)
+    x = quantize(rng.standard_normal((1, 13, 13, 64)).astype(np.float32), dtype)
+    cw = make_conv_weights(rng, 64, 64, 1, True)
+    for bad in ([430] if dtype == "f32" else [119 + 11, 133, 430]) + [408, 308]:     # 30: staggered; 33: 32x32x16; e = 4; K too short
+        with pytest.raises(ext.Y4Error):
+            run_conv_gpu(x, cw, 1, 1, "mish", dtype, tile=bad)
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_phased_tiles(dtype):
     """The phased kernel (conv_p8_kernel.h, schedule codes 8: staggered wave groups, 9: software-pipelined; and conv_l12_kernel.h,

@@ -220,3 +220,37 @@ def test_oracle_matches_the_reference_graph_with_80_classes():
     assert same.mean() > 0.98                      # rank swaps between near-tied scores of different classes only
     assert np.abs(np.sort(sc, axis=1) - np.sort(z["inf_scores"], axis=1)).max() < 1e-4
     assert len(meta["classes_seen"]) > 10          # the 80-class NMS really saw many classes
+
+
+def test_oracle_matches_the_reference_in_the_valid_below_100_regime():
+    """VERDICT r3 item 4(a).  Third reference-generated fixture (tests/golden/make_ref_sparse_fixture.py): the reference's own
+    Yolov4 graph with the objectness bias of its heads lowered until every image keeps 5..60 boxes -- CombinedNMS with partial zero
+    padding, the per-class cap and the rank-100 cut-off NOT binding (both other fixtures saturate at valid = 100).  The oracle
+    must reproduce valid counts, the zero padding, classes and rank order exactly, boxes / scores to float32 noise."""
+    from helpers import shift_objectness
+    from yolo4hip import weights as W
+    from yolo4hip.config import make_config
+    from yolo4hip.plan import build_plan
+    from oracle import forward as OF, decode_nms as OD
+    meta = json.load(open(os.path.join(GOLDEN, "ref_sparse.json")))
+    z = np.load(os.path.join(GOLDEN, "ref_416_sparse.npz"))
+    ncls, seed, size = meta["num_classes"], meta["seed"], meta["img_size"]
+    ws = shift_objectness(randomize_bn(W.synth_weights(build_plan(size, ncls), seed), seed), ncls, meta["objectness_shift"])
+    assert ramp_checksum(W.flatten(ws)[::97]) == pytest.approx(meta["weights_stream_checksum"], rel=1e-12)
+    cfg = make_config(size)
+    imgs = W.synth_images(meta["images"], size, seed)
+    heads = OF.yolo_model_forward(imgs, ws, ncls)
+    for s in range(3):
+        assert np.abs(heads[s][:1] - z[f"head{s}"]).max() < 2e-4, s
+    b, sc, c, v, _ki = OD.inference_from_heads(heads, ncls, cfg["anchors"], cfg["xyscale"], size)
+    assert v.tolist() == meta["valid"] == z["inf_valid"].tolist() and all(5 <= n <= 60 for n in meta["valid"])
+    for i, n in enumerate(meta["valid"]):
+        assert not b[i, n:].any() and not sc[i, n:].any() and not c[i, n:].any()           # zero padding behind `valid`
+        assert not z["inf_boxes"][i, n:].any() and not z["inf_scores"][i, n:].any()
+        assert np.array_equal(c[i, :n], z["inf_classes"][i, :n])                            # same kept set in the same order
+        assert np.abs(sc[i, :n] - z["inf_scores"][i, :n]).max() < 2e-5
+        assert np.abs(b[i, :n] - z["inf_boxes"][i, :n]).max() < 1e-4
+    # decode + NMS of the REFERENCE's own heads (image 0): identical decisions
+    b0, s0, c0, v0, _ = OD.inference_from_heads([z[f"head{s}"] for s in range(3)], ncls, cfg["anchors"], cfg["xyscale"], size)
+    n0 = meta["valid"][0]
+    assert int(v0[0]) == n0 and np.array_equal(c0[0], z["inf_classes"][0]) and np.abs(s0[0] - z["inf_scores"][0]).max() < 1e-5

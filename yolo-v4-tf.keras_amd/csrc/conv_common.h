@@ -53,6 +53,12 @@ struct ConvK {
     int fin2_cstride, fin2_coff, tail_split;
     int tail_k, tail_panel0;       // the tail reads tail_k input channels starting at LDS panel tail_panel0 (64 channels each)
     int touch;                     // != 0: the workgroups of an XCD touch this channel tile's weights into their L2 at start (weight_touch)
+    // split-K (ksplit > 1; plain launches only): split s of an output tile walks K-tiles [s nk / ksplit, (s + 1) nk / ksplit) and
+    // leaves its fp32 accumulators in `part`; the split that arrives last at the tile's counter adds them in index order and
+    // runs the epilogue (conv_igemm_kernel.h)
+    int ksplit;
+    float* part;                   // [ksplit][tiles][MREP * NREP][threads] float4
+    int* split_cnt;                // [tiles], zero between launches
 };
 
 template <int CPR> __device__ __forceinline__ int swz(int row) {

@@ -120,10 +120,14 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
         }
     }
     int tile = d->tile ? d->tile : pair ? (d->cout == 128 ? 20 : 19) : (k.ntail > 0 ? (d->cin % (128 / es) == 0 ? 3 : 4) : conv_pick_tile(d->dtype, k.M, d->cin, d->cout));
+    // split-K: tile id = base + 100 e runs the base tile with the K loop split 2^e ways (e = 1..3; kernels.h: splitk_*)
+    const int split_e = tile >= 100 ? tile / 100 : 0;
+    if (split_e) tile %= 100;
+    Y4_REQUIRE(split_e <= SPLITK_MAX_E, Y4_EINVAL, "conv2d: tile id %d: at most %d-way split-K", d->tile, 1 << SPLITK_MAX_E);
     Y4_REQUIRE(k.ntail == 0 || chain_tile(tile), Y4_EINVAL, "conv2d: tile id %d cannot head this chain", tile);
     Y4_REQUIRE(!pair || (pair_tile(tile) && kTiles[tile - 1].bn == d->cout), Y4_EINVAL, "conv2d: tile id %d cannot head this LDS pair", tile);
     Y4_REQUIRE(tile >= 1 && tile <= kNumTiles, Y4_EINVAL, "conv2d: tile id %d out of range", tile);
-    k.touch = weight_touch_enabled() ? 1 : 0;
+    k.touch = weight_touch_enabled() && !split_e ? 1 : 0;     // (a split walks only its share of the weight block)
     const TileCfg& tc = kTiles[tile - 1];
     Y4_REQUIRE(tile_ok(tc, d->dtype, d->cin, cout_pad), Y4_EINVAL,
                "conv2d: tile %d (bk bytes %d, bn %d) does not fit cin %d / cout_pad %d", tile, tc.bkb, tc.bn,
@@ -132,6 +136,20 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
     k.grid_n = (int)((round_up(d->cout, 8) + tc.bn - 1) / tc.bn);
     Y4_REQUIRE((int64_t)k.grid_n * tc.bn <= cout_pad, Y4_EINVAL, "conv2d: tile %d overruns the packed weight rows", tile);
     k.div_gridn = fastdiv_make((uint32_t)k.grid_n);
+    if (split_e) {
+        const int S = 1 << split_e;
+        const int64_t nwg = (int64_t)k.grid_m * k.grid_n, need = SPLITK_CNT_BYTES + nwg * S * tc.bm * tc.bn * 4;
+        Y4_REQUIRE(!pair && !(chain && chain->ntail > 0) && splitk_tile(tile), Y4_EINVAL,
+                   "conv2d: tile id %d cannot run split-K (plain launches of the 2..4-stage ring tiles only)", d->tile);
+        Y4_REQUIRE(k.K / (tc.bkb / es) >= 2 * S, Y4_EINVAL, "conv2d: tile id %d: %d K-tiles are too few for a %d-way split", d->tile,
+                   k.K / (tc.bkb / es), S);
+        Y4_REQUIRE(d->splitk_ws && nwg <= SPLITK_CNT_BYTES / 4 && (int64_t)d->splitk_ws_bytes >= need, Y4_EINVAL,
+                   "conv2d: tile id %d needs a split-K workspace of %lld bytes for %lld tiles (got %lld; at most %d tiles)", d->tile,
+                   (long long)need, (long long)nwg, (long long)d->splitk_ws_bytes, SPLITK_CNT_BYTES / 4);
+        k.ksplit = S;
+        k.split_cnt = (int*)d->splitk_ws;
+        k.part = (float*)((char*)d->splitk_ws + SPLITK_CNT_BYTES);
+    }
     k.out2 = (char*)d->out2; k.out2_cstride = d->out2_cstride; k.out2_coff = d->out2_coff; k.split = d->out2 ? d->split : 0;
     Y4_REQUIRE(!d->out2 || (d->split > 0 && d->split % 32 == 0 && d->split < d->cout && !d->res && !d->upsample && !d->out_f32 &&
                             d->out2_cstride % epc == 0 && d->out2_coff % epc == 0),

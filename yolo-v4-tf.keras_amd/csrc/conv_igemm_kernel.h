@@ -92,10 +92,20 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 
     // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous run of tiles with the
     //      channel tile fastest, so blocks sharing an activation row panel share an L2 (speed only).
+    // Split-K (p.ksplit = S > 1, plain launches at small batch): the S splits of a tile are S consecutive blocks of ONE XCD (their
+    // partial sums then meet in one L2); an XCD with fewer tiles than its neighbours leaves its surplus blocks idle.
     const int nwg = p.grid_m * p.grid_n;
-    int t;
+    int t, ks = 0;
     {
-        const int b = blockIdx.x, qq = nwg >> 3, rr = nwg & 7, xcd = b & 7, idx = b >> 3;
+        const int b = blockIdx.x, qq = nwg >> 3, rr = nwg & 7, xcd = b & 7;
+        int idx = b >> 3;
+        if constexpr (CHAIN == 0 && !PAIR && NST != 12 && NST != 32) {
+            if (p.ksplit > 1) {
+                ks = idx % p.ksplit;
+                idx /= p.ksplit;
+                if (idx >= qq + (xcd < rr ? 1 : 0)) return;       // (the whole block: uniform)
+            }
+        }
         t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
     }
     const int tile_m = (int)fastdiv((uint32_t)t, p.div_gridn), tile_n = t - tile_m * p.grid_n;
@@ -163,6 +173,17 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     // wave-uniform: does this wave skip the (partial) last A iteration?  (rows r0 + (A_IT-1)*RPI >= BM)
     const bool a_skip = A_PART && __builtin_amdgcn_readfirstlane(r0 + (A_IT - 1) * RPI >= BM ? 1 : 0) != 0;
     int ky = 0, kx = 0, c0b = 0, ktb = 0;          // staging cursor: tap, byte offset of c0, byte offset of k in the weights
+    int nk = p.K / BK;                             // K-tiles this block walks
+    if constexpr (CHAIN == 0 && !PAIR && NST != 12 && NST != 32) {
+        if (p.ksplit > 1) {                        // this split's K range: cursor to its first K-tile
+            const int kt0 = (int)((int64_t)ks * nk / p.ksplit), kt1 = (int)((int64_t)(ks + 1) * nk / p.ksplit);
+            const int e0 = kt0 * BK, tap = e0 / p.Cin;
+            ky = tap / p.ksize; kx = tap - ky * p.ksize;
+            c0b = (e0 - tap * p.Cin) * ES;
+            ktb = kt0 * BKB;
+            nk = kt1 - kt0;
+        }
+    }
     int a_vo[A_IT];
     auto set_tap = [&]() {
         const int tap_off = ((ky * p.W + kx) * p.in_cstride) * ES;
@@ -214,7 +235,6 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 #pragma unroll
         for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
     TR_LIFE(1, "s_memtime");
     if constexpr (M32) {
         // Same staging, same LDS image, same one-barrier 2-stage loop; the K-tile is 4 k-steps of 16 with 32x32 blocks:
@@ -495,6 +515,43 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         if (p.store_x) pair_store_tile<DT, MREP, NREP>(p, xl, xrow, XPANEL, mrow, p.M, chw, fg);
     } else {
         TR_LIFE(3, "s_memtime");
+        if constexpr (NST != 12 && NST != 32) {
+            if (p.ksplit > 1) {
+                // split-K: every split leaves its raw accumulators in `part` (one wave-wide 1 KB row per fragment); the split that
+                // arrives LAST at the tile's counter adds all of them in split order -- a fixed fp32 summation order whoever is
+                // last, but another one than the unsplit K loop's -- and runs the ordinary epilogue.  The counter is back at zero
+                // when the kernel ends (the next split-K launch re-uses it).
+                constexpr int FR = MREP * NREP;
+                f32x4* const mine = (f32x4*)p.part + ((size_t)ks * nwg + t) * FR * NT + tid;
+#pragma unroll
+                for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                    for (int j = 0; j < NREP; ++j) mine[(i * NREP + j) * NT] = acc[i][j];
+                __threadfence();                   // release: the partial sums before the counter
+                __syncthreads();                   // (also: every wave is done with the K loop's LDS)
+                int* const flag = (int*)smem;
+                if (tid == 0) {
+                    const int old = atomicAdd(p.split_cnt + t, 1);
+                    if (old == p.ksplit - 1) p.split_cnt[t] = 0;
+                    *flag = old == p.ksplit - 1;
+                }
+                __syncthreads();
+                if (*flag == 0) return;
+                __threadfence();                   // acquire: the other splits' partial sums
+                const f32x4* src = (const f32x4*)p.part + (size_t)t * FR * NT + tid;
+#pragma unroll
+                for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                    for (int j = 0; j < NREP; ++j) acc[i][j] = src[(i * NREP + j) * NT];
+                for (int sp = 1; sp < p.ksplit; ++sp) {
+                    src += (size_t)nwg * FR * NT;
+#pragma unroll
+                    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                        for (int j = 0; j < NREP; ++j) acc[i][j] += src[(i * NREP + j) * NT];
+                }
+            }
+        }
         const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.cout_store);
         conv_epilogue<DT, MREP, NREP>(p, acc, m0 + wm * WPX + frow, p.M, n0 + wn * WCH, fg, full);
         TR_LIFE(4, "s_memtime");
@@ -524,6 +581,15 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
             once.mark(bit);
         }
     }
+    if constexpr (CHAIN == 0 && !PAIR && NST != 12 && NST != 32) {
+        if (k.ksplit > 1) {
+            const int nwg = k.grid_m * k.grid_n, per_xcd = (nwg >> 3) + ((nwg & 7) ? 1 : 0);
+            hipLaunchKernelGGL(kern, dim3(8 * per_xcd * k.ksplit), dim3(64 * WM * WN), lds, stream, k);
+            Y4_CHECK_HIP(hipGetLastError());
+            return Y4_OK;
+        }
+    }
+    Y4_REQUIRE(k.ksplit <= 1, Y4_EINVAL, "conv2d: this tile / fusion cannot run split-K");
     hipLaunchKernelGGL(kern, dim3(k.grid_m * k.grid_n), dim3(64 * WM * WN), lds, stream, k);
     Y4_CHECK_HIP(hipGetLastError());
     return Y4_OK;

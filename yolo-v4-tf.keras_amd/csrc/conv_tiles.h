@@ -68,6 +68,21 @@ inline bool mfma32_tile(int tile) { return tile >= 1 && tile <= kNumTiles && kTi
 // 30-90 % slower than every other form on every layer: kept selectable by id as the record of that experiment)
 inline bool tuner_skips_tile(int tile) { return mfma32_tile(tile) || (tile >= 1 && tile <= kNumTiles && kTiles[tile - 1].nst == 10); }
 
+// Split-K (small batches: fewer tiles than compute units and a long serial K loop): tile id = base + 100 e runs base tile `base`
+// with its K loop split 2^e ways over 2^e workgroups per output tile.  A split run adds its partial sums in split order: a fixed
+// fp32 summation order, but not the unsplit loop's -- like the 32x32x16 tiles these ids are never offered by the bit-identical
+// tuner, only by y4_autotune after y4_set_splitk(h, 1).  Base tiles: the plain ring schedules (2..4 stages).
+constexpr int SPLITK_MAX_E = 3;
+constexpr int SPLITK_CNT_BYTES = 16 * 1024;          // 4096 tile counters in front of the partial sums
+constexpr size_t SPLITK_WS_BYTES = SPLITK_CNT_BYTES + (size_t)32 * 1024 * 1024;      // what an engine's workspace reserves for it
+inline bool splitk_tile(int base) { return base >= 1 && base <= kNumTiles && kTiles[base - 1].nst >= 2 && kTiles[base - 1].nst <= 4; }
+inline int tile_base(int tile) { return tile >= 100 ? tile % 100 : tile; }
+inline int tile_split_e(int tile) { return tile >= 100 ? tile / 100 : 0; }
+// a well-formed tile id (0 = heuristic)
+inline bool tile_id_ok(int tile) {
+    return tile >= 0 && tile_base(tile) <= kNumTiles && tile_split_e(tile) <= SPLITK_MAX_E && (tile < 100 || splitk_tile(tile_base(tile)));
+}
+
 // chain heads: the tiles with one wave column over 64 channels
 inline bool chain_tile(int tile) { return tile == 3 || tile == 4 || tile == 15; }
 

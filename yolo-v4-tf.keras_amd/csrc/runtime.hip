@@ -98,7 +98,9 @@ struct y4_ctx {
     View heads[3];
     // workspace layout
     size_t act_bytes = 0, wts_bytes = 0;
-    size_t zero_off = 0, dbox_off = 0, keys_off = 0, counts_off = 0, status_off = 0, scratch_off = 0;
+    size_t zero_off = 0, dbox_off = 0, keys_off = 0, counts_off = 0, status_off = 0, scratch_off = 0, splitk_off = 0;
+    // latency schedules: y4_autotune may pick split-K tile ids (conv_tiles.h); their counters + partial sums live at splitk_off
+    bool allow_splitk = false;
     uint32_t cand_cap = 0;
     char* act = nullptr;
     char* wts = nullptr;
@@ -535,6 +537,7 @@ void layout(y4_ctx& c) {
     c.counts_off = off; off = align256(off + nb * 4 * COUNT_STRIDE);
     c.status_off = off; off = align256(off + 256);
     c.scratch_off = off; off = align256(off + nb * (size_t)c.cfg.max_total * 28 + nb * 4);
+    c.splitk_off = off; off = align256(off + SPLITK_WS_BYTES);
     c.act_bytes = off;
     // ---- weights
     off = 0;
@@ -675,6 +678,7 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
     if (op.has_res) { d.res = buf_ptr(h, op.res, img0); d.res_cstride = op.res.cstride; d.res_coff = op.res.coff; }
     if (op.conv2 >= 0) { d.out2 = buf_ptr(h, op.out2, img0); d.out2_cstride = op.out2.cstride; d.out2_coff = op.out2.coff; d.split = op.split; }
     d.tile = chain ? chain->tile : op.tile;
+    d.splitk_ws = h->act + h->splitk_off; d.splitk_ws_bytes = SPLITK_WS_BYTES;
     if (chain && chain->lds_pair) {
         const Op& to = h->ops[chain->tail[0]];
         const Layer& TL = h->layers[to.conv];
@@ -858,6 +862,7 @@ int y4_bind_workspace(y4_handle h, void* act_dev, size_t act_bytes, void* wts_de
     h->weights_ready = false;
     Y4_CHECK_HIP(hipMemset(h->act + h->zero_off, 0, ZERO_PAGE_BYTES));
     Y4_CHECK_HIP(hipMemset(h->act + h->status_off, 0, 256));
+    Y4_CHECK_HIP(hipMemset(h->act + h->splitk_off, 0, SPLITK_CNT_BYTES));      // split-K tile counters: zero between launches
     return Y4_OK;
 }
 
@@ -1169,6 +1174,19 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
             if (ms == -2.f) { rc = Y4_EHIP; break; }
             if (ms >= 0.f && ms < best) { best = ms; best_tile = tile; }
         }
+        // latency schedules (y4_set_splitk): the same tiles with their K loop split 2 / 4 / 8 ways; the launcher refuses the ids
+        // that do not fit the layer (too few K-tiles, too many output tiles for the scratch), which reads as "does not fit" here
+        if (h->allow_splitk && rc == Y4_OK)
+            for (int tile = 1; tile <= ntiles && rc == Y4_OK; ++tile) {
+                if (tuner_skips_tile(tile) || !splitk_tile(tile)) continue;
+                for (int e = 1; e <= SPLITK_MAX_E; ++e) {
+                    set_tile(oi, tile + 100 * e);
+                    const float ms = time_op(oi, images_of(oi), false);
+                    if (ms == -2.f) { rc = Y4_EHIP; break; }
+                    if (ms < 0.f) break;                       // a wider split of this tile will not fit either
+                    if (ms < best) { best = ms; best_tile = tile + 100 * e; }
+                }
+            }
         set_tile(oi, best_tile);
         best_ms[oi] = best;
     }
@@ -1334,7 +1352,7 @@ int y4_set_tiles(y4_handle h, const int32_t* tiles, int count) {
             if (ch.head == oi) head_of = &ch;
         // a run's head carries two choices in one entry: -(run tile + 1000 * stand-alone tile); plain -t leaves the stand-alone one
         const int run_tile = v < 0 ? (-v) % 1000 : 0, own_tile = v < 0 ? (-v) / 1000 : v;
-        Y4_REQUIRE(own_tile <= conv_tile_count() && run_tile <= conv_tile_count() && (v >= 0 || (head_of && h->fuse_chains)), Y4_EINVAL,
+        Y4_REQUIRE(tile_id_ok(own_tile) && run_tile <= conv_tile_count() && (v >= 0 || (head_of && h->fuse_chains)), Y4_EINVAL,
                    "y4_set_tiles: tile id %d for conv %d", v, op.conv);
         if (head_of && h->fuse_chains) {      // < 0: chained with tile run_tile; > 0: separate kernels; 0: chained, heuristic tile
             head_of->enabled = v <= 0;
@@ -1420,6 +1438,12 @@ int y4_set_res_fusion_mask(y4_handle h, int mask) {
     h->res_on = mask != 0;
     h->res_enabled[0] = (mask & 1) != 0;
     h->res_enabled[1] = (mask & 2) != 0;
+    return Y4_OK;
+}
+
+int y4_set_splitk(y4_handle h, int on) {
+    if (int r = check_handle(h)) return r;
+    h->allow_splitk = on != 0;
     return Y4_OK;
 }
 

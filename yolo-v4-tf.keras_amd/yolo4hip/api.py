@@ -37,7 +37,7 @@ class _KerasLikeModel:
 
 class Yolov4(object):
     def __init__(self, weight_path=None, class_name_path='coco_classes.txt', config=yolo_config, *,
-                 dtype='f32', max_batch=32, synth_seed=0, device=None, device_preprocess=True):
+                 dtype='f32', max_batch=32, synth_seed=0, device=None, device_preprocess=True, tune=None):
         assert config['img_size'][0] == config['img_size'][1], 'not support yet'
         assert config['img_size'][0] % config['strides'][-1] == 0, 'must be a multiple of last stride'
         self.class_names = [line.strip() for line in open(class_name_path).readlines()]
@@ -55,6 +55,8 @@ class Yolov4(object):
         assert self.num_classes > 0, 'no classes detected!'
         self._dtype, self._max_batch, self._synth_seed, self._device = dtype, max_batch, synth_seed, device
         self._device_preprocess = device_preprocess
+        # tune-on-first-use of a shape without a shipped / cached schedule: on unless YOLO4HIP_TUNE=0 (or tune=False)
+        self._tune = (os.environ.get('YOLO4HIP_TUNE', '1') != '0') if tune is None else bool(tune)
         self.build_model(load_pretrained=True if self.weight_path else False)
 
     def build_model(self, load_pretrained=True):
@@ -62,16 +64,6 @@ class Yolov4(object):
         # alias_workspace: like the reference's Keras model, the facade keeps no intermediate activations (2.7x less HBM)
         self.engine = Engine(self.num_classes, self.config, max_batch=self._max_batch, dtype=self._dtype,
                              device=self._device, alias_workspace=True)
-        if self._dtype != 'f32':
-            # bit-identical scheduling choices (tests/test_gpu_forward.py): convs 0+1 in one kernel, CSP runs chained
-            if self.img_size[0] <= 640:
-                self.engine.set_stem_fusion(True)
-            self.engine.set_chain_fusion(True)
-            sched = self.engine.shipped_schedule()       # tuned tiles / stage kernel / residual-block kernels, if this shape has one
-            if sched is not None:
-                self.engine.set_stage_fusion(True)
-                self.engine.set_res_fusion(True)
-                self.engine.apply_schedule(sched)
         self.yolo_model = _KerasLikeModel(self.engine.forward_heads, 'yolo_model')
         print(f"nms iou: {self.config['iou_threshold']} score: {self.config['score_threshold']}")
         self.inference_model = _KerasLikeModel(self.engine.predict, 'inference_model')
@@ -82,6 +74,10 @@ class Yolov4(object):
         else:
             # the reference leaves Keras' random initialisation in place; ours is the seeded synthetic set
             self._set_weights(W.flatten(W.synth_weights(self.plan, self._synth_seed)))
+        # No silent un-tuned shapes: the tuned schedule that ships for this (size, classes, batch, dtype), else the one
+        # tuned on this machine before, else tune now -- once, cached on disk -- and say which is active.  16-bit schedules without
+        # split-K ids are bit-identical scheduling choices (tests/test_gpu_forward.py); `tune=False` keeps the built-in heuristic.
+        self.schedule_source = self.engine.ensure_schedule(tune=self._tune)
 
     def _set_weights(self, flat):
         """flat: the Darknet-order float32 stream (weights.flatten).  Kept on the host like Keras keeps its variables,

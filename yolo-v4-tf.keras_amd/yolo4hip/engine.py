@@ -517,6 +517,85 @@ class Engine:
         saved["path"] = path
         return saved
 
+    # ---------------------------------------------------------------- no silent un-tuned shapes
+    LATENCY_BATCH = 2          # engines for at most this many images are tuned for latency: split-K tile ids allowed
+
+    def schedule_cache_path(self):
+        """Where a schedule tuned on first use is kept: $YOLO4HIP_CACHE (default ~/.cache/yolo4hip) / schedules /
+        <side>_<classes>_<batch>_<dtype>_<gfx arch>_<library version>.json."""
+        import os
+        root = os.environ.get("YOLO4HIP_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "yolo4hip")
+        arch = self.torch.cuda.get_device_properties(self.device).gcnArchName.split(":")[0]
+        ver = self.lib.y4_version().decode().replace(" ", "_").replace("/", "_")
+        return os.path.join(root, "schedules", f"{self.img_size}_{self.num_classes}_{self.max_batch}_{self.dtype}_{arch}_{ver}.json")
+
+    def ensure_schedule(self, tune=True, verbose=True):
+        """Make sure this engine runs a TUNED schedule, and say which: (1) the one that ships with the package for this (image side,
+        classes, batch, dtype), else (2) the one a previous process tuned on this machine (`schedule_cache_path`), else (3) tune
+        now -- all fusions on, `autotune` on a synthetic batch of `max_batch` images, split-K offered for latency-sized engines
+        (`max_batch <= LATENCY_BATCH`) -- and write it to the cache.  The weights must be loaded.  Every schedule without split-K ids
+        gives the same bits; one with them is tested against the oracle instead (`"splitk": true` in the file).  Returns
+        (source, path): source in 'shipped' | 'cached' | 'tuned' | 'heuristic' (tune=False and nothing found)."""
+        import json
+        import os
+        def use(saved):
+            if self.dtype != "f32":
+                if self.img_size <= 640:
+                    self.set_stem_fusion(True)
+                self.set_chain_fusion(True)
+                self.set_stage_fusion(True)
+                self.set_res_fusion(True)
+            self.apply_schedule(saved)
+        src, path = "heuristic", None
+        saved = self.shipped_schedule()
+        if saved is not None and len(saved.get("tiles", [])) == 110:
+            use(saved)
+            src, path = "shipped", saved["path"]
+        else:
+            path = self.schedule_cache_path()
+            try:
+                saved = json.load(open(path))
+                if len(saved.get("tiles", [])) != 110:
+                    raise ValueError("stale")
+                use(saved)
+                src = "cached"
+            except (OSError, ValueError, ext.Y4Error):
+                saved = None
+            if saved is None and tune:
+                torch = self.torch
+                if self.dtype != "f32":
+                    if self.img_size <= 640:
+                        self.set_stem_fusion(True)
+                    self.set_chain_fusion(True)
+                    self.set_stage_fusion(True)
+                    self.set_res_fusion(True)
+                splitk = self.max_batch <= self.LATENCY_BATCH
+                self.set_splitk(splitk)
+                from . import weights as W
+                imgs = torch.from_numpy(W.synth_images(self.max_batch, self.img_size, seed=0)).to(self.device)
+                self.predict_device(imgs)                      # real activations in the workspace
+                tiles = self.autotune(self.max_batch, reps=3)
+                self.set_splitk(False)
+                saved = {"size": self.img_size, "classes": self.num_classes, "batch": self.max_batch, "dtype": self.dtype,
+                         "tiles": tiles, "stage_fusion": bool(self.stage_fusion_active()) if self.dtype != "f32" else False,
+                         "res_fusion_mask": int(self.res_fusion_mask()) if self.dtype != "f32" else 0, "in_flight": 1,
+                         "splitk": any(abs(t) % 1000 >= 100 or abs(t) // 1000 >= 100 for t in tiles),
+                         "tuned_on": torch.cuda.get_device_properties(self.device).gcnArchName}
+                try:
+                    os.makedirs(os.path.dirname(path), exist_ok=True)
+                    tmp = path + f".{os.getpid()}.tmp"
+                    json.dump(saved, open(tmp, "w"))
+                    os.replace(tmp, path)
+                except OSError:
+                    path = None                                # read-only home: tuned for this process only
+                src = "tuned"
+        self.schedule_source = (src, path)
+        if verbose:
+            what = {"shipped": "shipped with the package", "cached": "tuned earlier on this machine", "tuned": "tuned now (first use of this shape)",
+                    "heuristic": "NONE: built-in tile heuristic, fusion kernels off"}[src]
+            print(f"schedule: {what}" + (f" [{os.path.basename(path)}]" if path else ""))
+        return src, path
+
     def apply_schedule(self, saved):
         """Tiles / stage kernel / residual-block mask from a schedule dict (`shipped_schedule`, `bench.py --save-tiles`).  The
         fusion switches themselves (stem, chains, stage, residual blocks) must already be on: a schedule only narrows them."""
@@ -529,6 +608,14 @@ class Engine:
     def set_tiles(self, tiles):
         arr = (C.c_int32 * len(tiles))(*[int(t) for t in tiles])
         ext.check(self.lib.y4_set_tiles(self.handle, arr, len(tiles)))
+
+    def set_splitk(self, on=True):
+        """Latency schedules: let `autotune` also offer split-K tile ids (the K loop of a tile split over 2 / 4 / 8 workgroups; for
+        small batches, where the deep layers have fewer tiles than the GPU has compute units).  A split launch adds its partial
+        sums in another fp32 order than the unsplit loop, so the tuned schedule then is part of the numerical result; off by
+        default, and the schedules that ship for batch 1 say so (`"splitk": true`)."""
+        ext.check(self.lib.y4_set_splitk(self.handle, int(bool(on))))
+        self.splitk = bool(on)
 
     def set_subbatch(self, images, last_conv=16):
         """Run convs 0..last_conv over `images` images at a time (Infinity-Cache residency of the big early
