@@ -36,6 +36,7 @@ for key in shapes:
         print(key, "ships already (Y4_RETUNE=1 to tune it again)")
         eng.close()
         continue
+    eng.shipped_schedule = lambda: None            # (re)tune even when a file ships for this shape
     t0 = time.perf_counter()
     src, path = eng.ensure_schedule(tune=True, verbose=False)
     assert src == "tuned", (key, src)

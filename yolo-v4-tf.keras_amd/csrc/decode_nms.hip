@@ -356,6 +356,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
     if (tid == 0) sh[1] = 0;
     unsigned long long cutoff = ~0ull;           // exclusive upper bound of keys still to visit
     __syncthreads();
+    // every thread has read the image's candidate count: leave the counter at zero for the next step's decode (which therefore needs
+    // no memset launch in front of it; decode_launch clears only when a decode was NOT followed by its NMS)
+    if (tid == 0) p.counts[(size_t)n * COUNT_STRIDE] = 0;
 
     while (true) {
         // ---- how many keys remain below the cutoff?
@@ -542,8 +545,10 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
 
 size_t nms_lds_bytes(int max_total) { return (size_t)SORT_CAP * 24 + (size_t)max_total * (16 + 12) + 256 * 4 + 64; }
 
-int decode_launch(const DecodeK& k, hipStream_t stream) {
-    Y4_CHECK_HIP(hipMemsetAsync(k.counts, 0, sizeof(uint32_t) * k.N * COUNT_STRIDE, stream));
+int decode_launch(const DecodeK& k, hipStream_t stream, int clear_images) {
+    // the per-image candidate counters are zero between steps (nms_kernel resets its image's); `clear_images` > 0: the caller
+    // cannot vouch for that (first use, or a decode whose NMS never ran) -- clear that many counters first
+    if (clear_images > 0) Y4_CHECK_HIP(hipMemsetAsync(k.counts, 0, sizeof(uint32_t) * (size_t)clear_images * COUNT_STRIDE, stream));
     if (3 * (5 + k.C) <= 256) {
         const int64_t cells = (int64_t)k.N * k.cells_per_img;
         hipLaunchKernelGGL(decode_cell_kernel, dim3((int)((cells + 4 * DC_SCREEN - 1) / (4 * DC_SCREEN))), dim3(256), 0, stream, k);

@@ -94,7 +94,7 @@ struct DecodeK {
 struct NmsK {
     const float* dboxes;             // [N, nbox, 4]
     const unsigned long long* keys;  // [N, cap]
-    const uint32_t* counts;          // [N * COUNT_STRIDE]
+    uint32_t* counts;                // [N * COUNT_STRIDE]; a block resets its image's counter once it has read it
     uint32_t cap;
     int N, C, nbox, max_total, max_per_class;
     float iou_thr;
@@ -106,7 +106,9 @@ struct NmsK {
     uint32_t* status;                // [1] bit0: candidate list overflowed its capacity
     FastDiv div_c;                   // id -> (box, class) without integer division (ids < 2^31 checked at y4_create)
 };
-int decode_launch(const DecodeK& k, hipStream_t stream);
+int decode_launch(const DecodeK& k, hipStream_t stream, int clear_images);
+// tuner aid (latency schedules): streams `bytes` of `p` through the L2s so that the next launch starts on cold weights
+int l2_flush_launch(const void* p, size_t bytes, void* sink, hipStream_t stream);
 int nms_launch(const NmsK& k, hipStream_t stream);
 
 }  // namespace y4

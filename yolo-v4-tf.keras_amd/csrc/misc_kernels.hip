@@ -552,4 +552,20 @@ int fold_bn_launch(const float* rec, float* scale, float* shift, int cout, int c
     return Y4_OK;
 }
 
+// ---- tuner aid: stream a region through the L2s (y4_autotune for latency schedules times every candidate on cold weights, the
+// state a layer finds them in inside a real step: in no L2, at best in the Infinity Cache)
+__global__ void l2_flush_kernel(const u32x4_t* __restrict__ p, size_t n16, u32x4_t* sink) {
+    u32x4_t acc = {0u, 0u, 0u, 0u};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const u32x4_t v = p[i];
+        acc[0] ^= v[0]; acc[1] ^= v[1]; acc[2] ^= v[2]; acc[3] ^= v[3];
+    }
+    if (acc[0] == 0x9e3779b9u && acc[1] == 0x7f4a7c15u && acc[2] == 0x12345678u) *sink = acc;       // (never: keeps the loads alive)
+}
+int l2_flush_launch(const void* p, size_t bytes, void* sink, hipStream_t stream) {
+    hipLaunchKernelGGL(l2_flush_kernel, dim3(2048), dim3(256), 0, stream, (const u32x4_t*)p, bytes / 16, (u32x4_t*)sink);
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
 }  // namespace y4

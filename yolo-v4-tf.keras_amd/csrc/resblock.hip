@@ -28,15 +28,21 @@
 namespace y4 {
 
 constexpr int RB_ACT = (RB_ABL & 2) ? Y4_ACT_LEAKY : Y4_ACT_MISH;
-constexpr int RB_T = 16, RB_H = RB_T + 2, RB_HROWS = 336, RB_WAVES = 8;
+constexpr int RB_T = 16, RB_H = RB_T + 2, RB_WAVES = 8;
 
-template <int C> struct RbGeom {
+// TY = output rows of a workgroup's tile: 16 (the full 16x16 tile), or 8 / 4 -- a HALF / QUARTER tile (the same 16 columns): the
+// last, partial round of a launch runs as part tiles on the compute units it would leave idle (resblock_dispatch), and so does a
+// batch with fewer tiles than compute units.  Same MFMAs per output pixel in the same order: bit-identical to the full tile.
+template <int C, int TY = RB_T> struct RbGeom {
+    static constexpr int HR = TY + 2;                  // halo'd rows of the tile (halo'd width: RB_H)
+    static constexpr int HROWS = (HR * RB_H + 15) / 16 * 16;              // pixel rows of the LDS tile (padded to a fragment)
+    static constexpr int NFA = HR + (2 * HR + 15) / 16;                  // pixel fragments of the 1x1 phase: rows + the two halo columns
     static constexpr int CPR = C / 8;                  // 16-byte chunks of data per pixel row of the LDS tile
     // Rows are PADDED by one chunk instead of XOR-swizzled: 16 lanes reading one chunk of 16 consecutive rows then hit 16
     // different 4-bank groups for ANY first row and chunk (row stride 272 B = 68 banks = 4 mod 64; 144 B = 36 banks), and
     // every fragment address of the 3x3 loop is "lane base + compile-time constant" -- no address VALU, one base VGPR.
     static constexpr int ROWB = C * 2 + 16;            // bytes per pixel row incl. the pad chunk
-    static constexpr int XT_PIECES = (RB_HROWS * (CPR + 1) + 63) / 64;     // 1 KB LDS-DMA pieces that fill the tile
+    static constexpr int XT_PIECES = (HROWS * (CPR + 1) + 63) / 64;        // 1 KB LDS-DMA pieces that fill the tile
     static constexpr int NF = C / 16;                  // output-channel fragments of a conv
     static constexpr int KS1 = C / 32;                 // MFMA k-steps of the 1x1 conv
     // The weights of both convs form ONE stream of equal steps of 64 input channels (2 MFMA k-steps x NF fragments x 1 KB):
@@ -52,8 +58,9 @@ template <int C> struct RbGeom {
     static constexpr int BLOB_BYTES = AFF_PAD + NSTEPS * STEP_BYTES;      // [affine | W1 | W3]
     static constexpr int L_AFF = 0, L_RING = AFF_PAD, L_XT = L_RING + RING * STEP_BYTES;
     static constexpr int LDS = L_XT + XT_PIECES * 1024;
-    static constexpr int WN = NF / 4, WM = RB_WAVES / WN, MREP = RB_T / WM;       // wave grid of the 3x3 phase; NREP = 4
-    static_assert(LDS <= 160 * 1024 && MREP * WM == RB_T && PPW >= 1 && PPW * RB_WAVES * 1024 == STEP_BYTES, "resblock geometry");
+    static constexpr int WN = NF / 4, WM = RB_WAVES / WN, MREP = TY / WM;         // wave grid of the 3x3 phase; NREP = 4
+    static_assert(LDS <= 160 * 1024 && MREP >= 1 && MREP * WM == TY && PPW >= 1 && PPW * RB_WAVES * 1024 == STEP_BYTES && NFA <= 3 * RB_WAVES,
+                  "resblock geometry");
 };
 
 struct ResBlockK {
@@ -64,14 +71,16 @@ struct ResBlockK {
     unsigned in_bytes;
     int N, S;
     int tiles_x, tiles_per_img, ntiles;
+    int t_begin, t_end;          // this launch's range of PART tiles: part tile u = 16x16 tile u / (16 / TY), rows (u % (16 / TY)) * TY .. + TY
     int touch;                   // weight touch (conv_common.h) of the block's blob at kernel start
 };
 
-template <int DT, int C>
+template <int DT, int C, int TY>
 __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kernel(const ResBlockK p) {
     using E = Elem<DT>;
     using T = typename E::type;
-    using G = RbGeom<C>;
+    using G = RbGeom<C, TY>;
+    constexpr int PARTS = RB_T / TY;
     constexpr int ROWB = G::ROWB, CPR = G::CPR, NF = G::NF, MREP = G::MREP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,8 +92,17 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
 
     const int GR = gridDim.x, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
     const int nb_x = (GR - xcd + 7) >> 3;
-    const int t_lo = (int)((int64_t)p.ntiles * xcd / 8), t_hi = (int)((int64_t)p.ntiles * (xcd + 1) / 8);
+    const int span = p.t_end - p.t_begin;
+    const int t_lo = p.t_begin + (int)((int64_t)span * xcd / 8), t_hi = p.t_begin + (int)((int64_t)span * (xcd + 1) / 8);
     int t = t_lo + bi;
+    // part tile -> image, tile row / column of the 16x16 tiling, first output row
+    auto locate = [&](int u, int& n, int& y_out0, int& tx) {
+        const int full = u / PARTS, part = u - full * PARTS;
+        n = full / p.tiles_per_img;
+        const int rem = full - n * p.tiles_per_img, ty = rem / p.tiles_x;
+        tx = rem - ty * p.tiles_x;
+        y_out0 = ty * RB_T + part * TY;
+    };
 
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.blob, G::BLOB_BYTES);
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
@@ -107,15 +125,15 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
     };
     // halo'd tile of x -> XT (out-of-image pixels and the 12 spare rows read as zeros)
     auto load_x = [&](int tile) {
-        const int n = tile / p.tiles_per_img, rem = tile - n * p.tiles_per_img;
-        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        const int y0 = ty * RB_T - 1, x0 = tx * RB_T - 1;
+        int n, yo, tx;
+        locate(tile, n, yo, tx);
+        const int y0 = yo - 1, x0 = tx * RB_T - 1;
         for (int u = wave; u < G::XT_PIECES; u += RB_WAVES) {
             const int slot = u * 64 + lane;                         // 16-byte slot of the padded tile, written lane-linearly
             const int hp = slot / (CPR + 1), ch = slot - hp * (CPR + 1);
             const int hy = hp / RB_H, hx = hp - hy * RB_H;
             const int gy = y0 + hy, gx = x0 + hx;
-            const bool ok = ch < CPR && hp < RB_H * RB_H && (unsigned)gy < (unsigned)p.S && (unsigned)gx < (unsigned)p.S;
+            const bool ok = ch < CPR && hp < G::HR * RB_H && (unsigned)gy < (unsigned)p.S && (unsigned)gx < (unsigned)p.S;
             const int off = (((n * p.S + gy) * p.S + gx) * p.in_cstride + p.in_coff + ch * 8) * 2;
             buffer_load16_lds(rs_in, XT + __builtin_amdgcn_readfirstlane(u * 1024), ok ? off : (int)0x80000000, 0);
         }
@@ -123,8 +141,8 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
     if (t < t_hi) { load_x(t); stage_w(0); stage_w(1); stage_w(2); }
 
     for (; t < t_hi; t += nb_x) {
-        const int n = t / p.tiles_per_img, rem = t - n * p.tiles_per_img;
-        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        int n, y_out0, tx;
+        locate(t, n, y_out0, tx);
         wait_vmcnt_then_barrier<0>();          // x tile and stream steps 0..2 landed; all waves left the previous tile
 
         // ================= phase A: t = Mish(BN(conv1x1(x))) on the halo'd tile, IN PLACE; zero outside the image.
@@ -138,11 +156,11 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
             for (int k = 0; k < NFR; ++k) {
                 const int f = wave + k * RB_WAVES;
                 int hy, hx;
-                if (f < RB_H) { hy = f; hx = 1 + q; }
-                else { const int pp = min((f - RB_H) * 16 + q, 2 * RB_H - 1); hy = pp >> 1; hx = (pp & 1) * (RB_H - 1); }
+                if (f < G::HR) { hy = f; hx = 1 + q; }
+                else { const int pp = min((f - G::HR) * 16 + q, 2 * G::HR - 1); hy = pp >> 1; hx = (pp & 1) * (RB_H - 1); }
                 const int r = hy * RB_H + hx;
                 row[k] = XT + r * ROWB;
-                const int gy = ty * RB_T - 1 + hy, gx = tx * RB_T - 1 + hx;
+                const int gy = y_out0 - 1 + hy, gx = tx * RB_T - 1 + hx;
                 inside[k] = (unsigned)gy < (unsigned)p.S && (unsigned)gx < (unsigned)p.S;
             }
             f32x4 acc[NFR][NF];
@@ -184,9 +202,10 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
                 }
             }
         };
-        if (!(RB_ABL & 1)) {
-            if (wave + 2 * RB_WAVES < RB_HROWS / 16) phase_a(std::integral_constant<int, 3>{});
-            else phase_a(std::integral_constant<int, 2>{});
+        if (!(RB_ABL & 1)) {                   // NFA fragments over 8 waves: fragments wave, wave + 8, wave + 16 (wave-uniform counts)
+            if (wave + 2 * RB_WAVES < G::NFA) phase_a(std::integral_constant<int, 3>{});
+            else if (wave + RB_WAVES < G::NFA) phase_a(std::integral_constant<int, 2>{});
+            else if (wave < G::NFA) phase_a(std::integral_constant<int, 1>{});
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -201,7 +220,7 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
             bool live[MREP];
 #pragma unroll
             for (int i = 0; i < MREP; ++i) {
-                const int gy = ty * RB_T + wm * MREP + i, gx = tx * RB_T + q;
+                const int gy = y_out0 + wm * MREP + i, gx = tx * RB_T + q;
                 live[i] = gy < p.S && gx < p.S;
                 pix[i] = ((int64_t)n * p.S + (live[i] ? gy : 0)) * p.S + (live[i] ? gx : 0);
                 const T* rp = (const T*)p.in + pix[i] * p.in_cstride + p.in_coff;
@@ -304,6 +323,30 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
 bool resblock_supported(int dtype, int c) { return dtype != Y4_F32 && (c == 128 || c == 64); }
 size_t resblock_blob_bytes(int c) { return c == 128 ? RbGeom<128>::BLOB_BYTES : RbGeom<64>::BLOB_BYTES; }
 
+template <int DT, int C, int TY>
+static int resblock_run(const ResBlockK& k, int slots, hipStream_t stream) {
+    // `slots` workgroups fit the GPU at once (the same number on every XCD); persistent over this launch's part tiles
+    int grid = slots;
+    const int span = k.t_end - k.t_begin;
+    if (grid > ((span + 7) & ~7)) grid = (span + 7) & ~7;
+    if (grid < 8) grid = 8;
+    constexpr int lds = RbGeom<C, TY>::LDS;
+    static PerDeviceOnce once;
+    if (const uint64_t bit = once.due()) {
+        Y4_CHECK_HIP(hipFuncSetAttribute((const void*)resblock_kernel<DT, C, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        once.mark(bit);
+    }
+    hipLaunchKernelGGL((resblock_kernel<DT, C, TY>), dim3(grid), dim3(64 * RB_WAVES), lds, stream, k);
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+// Y4_RB_PARTS=0 runs every tile as a full 16x16 tile (A/B measurements; results are the same either way)
+static bool rb_parts_enabled() {
+    static const bool on = [] { const char* e = getenv("Y4_RB_PARTS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <int DT, int C>
 static int resblock_dispatch(ResBlockK& k, hipStream_t stream) {
     static int n_cus[64] = {0};
@@ -314,18 +357,29 @@ static int resblock_dispatch(ResBlockK& k, hipStream_t stream) {
         Y4_CHECK_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
         n_cus[dev & 63] = v > 0 ? v : 256;
     }
-    // one workgroup per CU for C = 128 (LDS), two for C = 64 (79 KB each: their phases overlap); the same number on every XCD
-    int grid = (n_cus[dev & 63] & ~7) * (C == 64 ? 2 : 1);
-    if (grid < 8) grid = 8;
-    if (grid > ((k.ntiles + 7) & ~7)) grid = (k.ntiles + 7) & ~7;
-    static PerDeviceOnce once;
-    if (const uint64_t bit = once.due()) {
-        Y4_CHECK_HIP(hipFuncSetAttribute((const void*)resblock_kernel<DT, C>, hipFuncAttributeMaxDynamicSharedMemorySize, RbGeom<C>::LDS));
-        once.mark(bit);
+    // one workgroup per CU for C = 128 (LDS), two for C = 64 (79 KB each: their phases overlap)
+    const int slots = (n_cus[dev & 63] & ~7) * (C == 64 ? 2 : 1);
+    // Round quantisation: 800 tiles on 256 slots are 3 full rounds and one round on 32 slots (4 tile times for 3.1 of work).  The
+    // tiles of the partial last round run as half / quarter tiles (8 / 4 output rows: the halo'd 1x1 phase is repeated per part,
+    // the 3x3 phase splits) when all their parts fit one round; a launch with fewer tiles than slots is split the same way.
+    constexpr int MAXP = C == 128 ? 4 : 2;                 // C = 64: eight wave rows need at least 8 output rows
+    const int full = k.ntiles / slots * slots, rem = k.ntiles - full;
+    int parts = 1;
+    if (rb_parts_enabled() && rem > 0)
+        for (int pp = 2; pp <= MAXP; pp *= 2)
+            if (rem * pp <= slots) parts = pp;
+    if (parts == 1) {
+        k.t_begin = 0; k.t_end = k.ntiles;
+        return resblock_run<DT, C, RB_T>(k, slots, stream);
     }
-    hipLaunchKernelGGL((resblock_kernel<DT, C>), dim3(grid), dim3(64 * RB_WAVES), RbGeom<C>::LDS, stream, k);
-    Y4_CHECK_HIP(hipGetLastError());
-    return Y4_OK;
+    if (full > 0) {
+        k.t_begin = 0; k.t_end = full;
+        if (int r = resblock_run<DT, C, RB_T>(k, slots, stream)) return r;
+    }
+    k.t_begin = full * parts; k.t_end = k.ntiles * parts;
+    if (parts == 2) return resblock_run<DT, C, RB_T / 2>(k, slots, stream);
+    if constexpr (MAXP >= 4) return resblock_run<DT, C, RB_T / 4>(k, slots, stream);
+    return Y4_EINVAL;
 }
 
 int resblock_launch(int dtype, int c, const void* in, int n, int side, int in_cstride, int in_coff, const void* blob, void* out,
