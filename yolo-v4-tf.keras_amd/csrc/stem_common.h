@@ -46,6 +46,27 @@ template <bool EXACT32> __device__ __forceinline__ void img_run8(const uint8_t* 
     for (int e = 0; e < 8; ++e) v[e] = unit_from_u8<EXACT32>((w[e >> 2] >> (8 * (e & 3))) & 0xffu);
 }
 
+// The same through a raw buffer descriptor over the whole image batch and a 32-bit ELEMENT offset (stem_down.hip's preloaded
+// tiles: a 64-bit pointer per load in flight costs two registers each).  Loads need only the element's own alignment.
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+__device__ __forceinline__ void img_buf_run8(__amdgpu_buffer_rsrc_t rs, const float*, uint32_t off, float v[8]) {
+    const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 4u), 0, 0);
+    const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 4u + 16u), 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(a[e]); v[4 + e] = __uint_as_float(b[e]); }
+}
+__device__ __forceinline__ void img_buf_run8(__amdgpu_buffer_rsrc_t rs, const uint8_t*, uint32_t off, float v[8]) {
+    const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = unit_from_u8<false>((w[e >> 2] >> (8 * (e & 3))) & 0xffu);
+}
+__device__ __forceinline__ float img_buf_elem(__amdgpu_buffer_rsrc_t rs, const float*, uint32_t off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(off * 4u), 0, 0));
+}
+__device__ __forceinline__ float img_buf_elem(__amdgpu_buffer_rsrc_t rs, const uint8_t*, uint32_t off) {
+    return unit_from_u8<false>((uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)off, 0, 0));
+}
+
 // This lane's 8 K values for pixel (y, x) of the image at `img` (H x W x 3 elements).
 // EDGE = false: rows y-1..y+1 and columns x-1..x+1 are inside the image for every lane of the wave.
 template <bool EDGE, bool EXACT32 = false, class IMG = float>

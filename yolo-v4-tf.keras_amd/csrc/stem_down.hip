@@ -36,6 +36,24 @@ struct StemDownK {
 constexpr int SD_WAVES = 16, SD_WM = 8, SD_WN = 2;      // 1024 threads: the block is alone on its CU (LDS), so it
                                                         // brings its own latency hiding
 constexpr int SD_UNROLL = 4;                            // stem tiles whose gathers are in flight together
+#ifndef SD_PRELOAD
+// 1: on a "regular" output row (two new conv-0 rows, every patch inside the image) a wave's first SD_PRE stem tiles are loaded
+// into registers one output row AHEAD -- issued before the previous row's conv phase, which hides their round trip -- and its
+// remaining tiles are requested first thing in the stem phase, so that they land while the preloaded ones are converted,
+// multiplied and stored.  Before, every wave of the workgroup started a row by waiting for its own loads (the stem phase of a
+// row was 40 % idle: in-kernel trace).  Same values through the same MFMAs: bit-identical.
+#define SD_PRELOAD 1
+#endif
+#ifndef SD_TAPBAR
+#define SD_TAPBAR 1
+#endif
+#ifndef SD_PRE_TILES
+#define SD_PRE_TILES 2
+#endif
+constexpr int SD_PRE = SD_PRE_TILES;                    // preloaded stem tiles per wave (8 registers each across the conv phase)
+// the generic stem loop then serves only the rows that are NOT regular (the first row of a band or image, the last of an image:
+// ~2 % of the rows): two tiles in flight instead of four keep its register peak below what the preloaded tiles leave free
+constexpr int SD_GEN_UNROLL = SD_PRELOAD ? 2 : SD_UNROLL;
 
 static __device__ __forceinline__ int sd_swz(int row) { return (row >> 1) & 3; }
 
@@ -92,24 +110,71 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
     const int64_t img_bytes = (int64_t)p.N * S * S * 3 * (int64_t)sizeof(IMG);
     const __amdgpu_buffer_rsrc_t rs_img = make_rsrc(p.img, img_bytes < 0xffffffffll ? (unsigned)img_bytes : 0xffffffffu);
     const u32x4 wf0 = p.stem_frag[lane], wf1 = p.stem_frag[64 + lane];
-    float sc0[8], sh0[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { sc0[c] = p.s0_scale[g * 8 + c]; sh0[c] = p.s0_shift[g * 8 + c]; }
     const int wm = wave % SD_WM, wn = wave / SD_WM;
-    float sc1[8], sh1[8];
+    // BN scale / shift of both convs live in LDS ([scale0 32 | shift0 32 | scale1 64 | shift1 64] floats behind the prefetch scratch)
+    // and are read where they are used, once per output row: 32 registers that are not held across the other conv's phase
+    float* const lds_aff = (float*)(lds_s + 3 * 2 * PW * 64 + 1024);
+    if (tid < 32) { lds_aff[tid] = p.s0_scale[tid]; lds_aff[32 + tid] = p.s0_shift[tid]; }
+    else if (tid < 96) { lds_aff[64 + tid - 32] = p.s1_scale[tid - 32]; lds_aff[128 + tid - 32] = p.s1_shift[tid - 32]; }
+    __syncthreads();
+    auto read_aff8 = [&](const float* tab, float (&dst)[8]) {
+        const f32x4 a = *(const f32x4*)tab, b = *(const f32x4*)(tab + 4);
 #pragma unroll
-    for (int c = 0; c < 8; c += 4) {
-        const f32x4 s4 = *(const f32x4*)(p.s1_scale + g * 16 + wn * 8 + c);
-        const f32x4 h4 = *(const f32x4*)(p.s1_shift + g * 16 + wn * 8 + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { sc1[c + e] = s4[e]; sh1[c + e] = h4[e]; }
-    }
+        for (int e = 0; e < 4; ++e) { dst[e] = a[e]; dst[4 + e] = b[e]; }
+    };
 
 #ifdef SD_TRACE
     unsigned long long tr_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    // ---- the regular-row machinery (SD_PRELOAD): tile k of this wave on a row with two new conv-0 rows is tile wave + 16 k of
+    //      2 * (S / 16); a tile past the end repeats the last one (same values to the same slots)
+    const int sd_tpr = S >> 4, sd_nt = 2 * sd_tpr;
+    const int sd_lane_off = g < 3 ? ((g - 1) * S + q - 1) * 3 : (-S + q + 1) * 3 + 2;
+    auto reg_tile = [&](int k, int ho_, int& xt, int& y, int& slot) {
+        const int tile = min(wave + SD_WAVES * k, sd_nt - 1);
+        const int rr = tile >= sd_tpr ? 1 : 0;
+        xt = tile - rr * sd_tpr; y = 2 * ho_ + rr; slot = (2 * ho_ + 1 + rr) % 3;
+    };
+    // (the patch address as ONE 32-bit element offset from the batch's first image: a 64-bit pointer per load in flight costs two
+    //  registers each, and a spilled address is reloaded through scratch, whose wait also waits for every patch still in flight)
+    // `lane_lo`: sd_lane_off seen through an empty asm once per output row.  Every tile's column offset (xt * 48 + lane offset) and
+    // strip address is the same on every row for a given wave, so the compiler would compute them once, keep ~10 registers for them
+    // across the whole loop and -- at this kernel's 128-register cap -- spill them; their reloads then sit between the preloads and
+    // wait for them (a scratch load shares the vector-memory counter).  Recomputing them costs one multiply-add per tile.
+    int lane_lo = sd_lane_off;
+    auto reg_load = [&](int n_, int y, int xt, float (&v)[8]) {
+        const uint32_t off = (uint32_t)(((n_ * S + y) * S + xt * 16) * 3 + lane_lo);
+        if (g < 3) img_buf_run8(rs_img, (const IMG*)nullptr, off, v);
+        else {
+            v[0] = img_buf_elem(rs_img, (const IMG*)nullptr, off);
+            v[1] = img_buf_elem(rs_img, (const IMG*)nullptr, off + (uint32_t)(S * 3));
+            v[2] = img_buf_elem(rs_img, (const IMG*)nullptr, off + (uint32_t)(2 * S * 3));
+#pragma unroll
+            for (int e = 3; e < 8; ++e) v[e] = 0.f;
+        }
+    };
+    // a patch that touches the image border, element by element (stem_common.h: stem_gather<EDGE = true>), same addressing
+    auto edge_load = [&](int n_, int y, int x, float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int ky, j;
+            stem_k_slot(g, e, ky, j);
+            const int kx = j / 3, ci = j - kx * 3;
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            const bool ok = ky >= 0 && (unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S;
+            v[e] = ok ? img_buf_elem(rs_img, (const IMG*)nullptr, (uint32_t)(((n_ * S + yy) * S + xx) * 3 + ci)) : 0.f;
+        }
+    };
+    auto reg_row = [&](int row_i) {                   // is output row `row_i` of this band regular?
+        if (!SD_PRELOAD || row_i >= r_end || row_i == r_begin) return false;
+        const int ho_ = row_i % Wo;
+        return ho_ >= 1 && ho_ <= Wo - 2;
+    };
+    float vpre[SD_PRE][8];
+    bool have_pre = false;
     for (int orow_i = r_begin; orow_i < r_end; ++orow_i) {
     const int n = orow_i / Wo, ho = orow_i - n * Wo;
+    asm volatile("" : "+v"(lane_lo));
 #ifdef SD_TRACE
     const bool tr_on = blockIdx.x == SD_TR_WG && orow_i - r_begin >= SD_TR_R0 && orow_i - r_begin < SD_TR_R0 + 4;
 #endif
@@ -118,20 +183,68 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
     const int ry_first = (orow_i == r_begin || ho == 0) ? 0 : 1;
     // ---- 2. c0 rows -> LDS ring (MFMA stem: stem_mfma_kernel's arithmetic, stem_common.h's K layout)
     {
+        float sc0[8], sh0[8];
+        read_aff8(lds_aff + g * 8, sc0);
+        read_aff8(lds_aff + 32 + g * 8, sh0);
         const float* sc = sc0; const float* sh = sh0;
         const int tiles_per_row = S >> 4;
         const int ntiles = (3 - ry_first) * tiles_per_row;
-        const IMG* const img_n = (const IMG*)p.img + (int64_t)n * S * S * 3;
-        // this lane's share of a pixel's patch, relative to the tile's first pixel (stem_common.h): groups 0..2 read
-        // floats 0..7 of row y+g-1's run, group 3 float 8 of the three runs
-        const int lane_off = g < 3 ? ((g - 1) * S + q - 1) * 3 : (-S + q + 1) * 3 + 2;
-        for (int t0 = wave; t0 < ntiles; t0 += SD_WAVES * SD_UNROLL) {
-            float v[SD_UNROLL][8];
-            int xs[SD_UNROLL], rys[SD_UNROLL];          // rys: ring slot 0..2 of the c0 row | 4 if that row is outside the image
-            int ys[SD_UNROLL], xts[SD_UNROLL];
+        // (this lane's share of a pixel's patch, relative to the tile's first pixel -- stem_common.h: groups 0..2 read floats 0..7
+        // of row y+g-1's run, group 3 float 8 of the three runs -- is sd_lane_off above)
+        // a regular row's first tiles were loaded into `vpre` before the previous row's conv phase (have_pre was decided there)
+        if (have_pre) {
+            constexpr int NB = 5 - SD_PRE;              // tiles behind the preloaded ones (S <= 640: at most 5 per wave)
+            const bool has_b = wave + SD_WAVES * SD_PRE < sd_nt;      // wave-uniform
+            float vb[NB][8];
+            int xtb[NB], yb[NB], slb[NB];
+            if (has_b) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    reg_tile(SD_PRE + k, ho, xtb[k], yb[k], slb[k]);
+                    reg_load(n, yb[k], xtb[k], vb[k]);
+                }
+            }
+            int xta[SD_PRE], ya[SD_PRE], sla[SD_PRE];
+#pragma unroll
+            for (int k = 0; k < SD_PRE; ++k) {
+                reg_tile(k, ho, xta[k], ya[k], sla[k]);
+            }
+            auto finish = [&](float (&v)[8], int xt, int slot) {
+                const int x = xt * 16 + q;
+                if (xt == 0 || xt == sd_tpr - 1) {      // wave-uniform: the conv's zero padding left / right of the image
+                    const bool lo = g < 3 ? x == 0 : x == S - 1, hi = x == S - 1;
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) v[e] = lo ? 0.f : v[e];
+                    v[6] = hi ? 0.f : v[6];
+                    v[7] = hi ? 0.f : v[7];
+                }
+                u32x4 xf;
+                E::store_chunk(&xf, v);
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                Mma<DT>::run(a0, wf0, xf);
+                Mma<DT>::run(a1, wf1, xf);
+                float o[8];
+                bn_act4<true, Y4_ACT_LEAKY>(a0, sc, sh, o);
+                bn_act4<true, Y4_ACT_LEAKY>(a1, sc + 4, sh + 4, o + 4);
+                u32x4 packed;
+                E::store_chunk(&packed, o);
+                const int plane = x & 1, row = (slot * 2 + plane) * PW + ((x + plane) >> 1);
+                *(u32x4*)(lds_s + row * 64 + ((g ^ sd_swz(row)) * 16)) = packed;
+            };
+#pragma unroll
+            for (int k = 0; k < SD_PRE; ++k) finish(vpre[k], xta[k], sla[k]);
+            if (has_b) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) finish(vb[k], xtb[k], slb[k]);
+            }
+        } else
+        for (int t0 = wave; t0 < ntiles; t0 += SD_WAVES * SD_GEN_UNROLL) {
+            float v[SD_GEN_UNROLL][8];
+            int xs[SD_GEN_UNROLL], rys[SD_GEN_UNROLL];          // rys: ring slot 0..2 of the c0 row | 4 if that row is outside the image
+            int ys[SD_GEN_UNROLL], xts[SD_GEN_UNROLL];
             bool fast = true;                           // no tile of the batch is within 2 rows of the top / bottom border
 #pragma unroll
-            for (int u = 0; u < SD_UNROLL; ++u) {
+            for (int u = 0; u < SD_GEN_UNROLL; ++u) {
                 // wave-uniform (scalar registers).  Past the end: redo the last tile (same values to the same slots)
                 const int tile = min(t0 + u * SD_WAVES, ntiles - 1);
                 const int rr = (tile >= tiles_per_row) + (tile >= 2 * tiles_per_row);
@@ -159,23 +272,12 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
             if (fast) {
                 // branch-free batch: all loads back to back (one divergent if/else around them), then all MFMAs, then
                 // the epilogues, so that neither the load nor the MFMA latency is paid per tile
-                if (g < 3) {
 #pragma unroll
-                    for (int u = 0; u < SD_UNROLL; ++u)
-                        img_run8<false>(img_n + (lane_off + (ys[u] * S + xts[u] * 16) * 3), v[u]);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < SD_UNROLL; ++u) {
-                        const IMG* pp = img_n + (lane_off + (ys[u] * S + xts[u] * 16) * 3);
-                        v[u][0] = img_elem<false>(pp); v[u][1] = img_elem<false>(pp + S * 3); v[u][2] = img_elem<false>(pp + 2 * S * 3);
-#pragma unroll
-                        for (int e = 3; e < 8; ++e) v[u][e] = 0.f;
-                    }
-                }
+                for (int u = 0; u < SD_GEN_UNROLL; ++u) reg_load(n, ys[u], xts[u], v[u]);
                 // left / right image border: the run's pixel x-1 (floats 0..2) or x+1 (floats 6, 7 and group 3's values)
                 // was read from the neighbouring row -- it is the conv's zero padding
 #pragma unroll
-                for (int u = 0; u < SD_UNROLL; ++u) {
+                for (int u = 0; u < SD_GEN_UNROLL; ++u) {
                     if (xts[u] != 0 && xts[u] != tiles_per_row - 1) continue;        // wave-uniform
                     const bool lo = g < 3 ? xs[u] == 0 : xs[u] == S - 1, hi = xs[u] == S - 1;
 #pragma unroll
@@ -183,9 +285,9 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
                     v[u][6] = hi ? 0.f : v[u][6];
                     v[u][7] = hi ? 0.f : v[u][7];
                 }
-                f32x4 a0[SD_UNROLL], a1[SD_UNROLL];
+                f32x4 a0[SD_GEN_UNROLL], a1[SD_GEN_UNROLL];
 #pragma unroll
-                for (int u = 0; u < SD_UNROLL; ++u) {
+                for (int u = 0; u < SD_GEN_UNROLL; ++u) {
                     u32x4 xf;
                     E::store_chunk(&xf, v[u]);
                     a0[u] = a1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -193,15 +295,15 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
                     Mma<DT>::run(a1[u], wf1, xf);
                 }
 #pragma unroll
-                for (int u = 0; u < SD_UNROLL; ++u) {
+                for (int u = 0; u < SD_GEN_UNROLL; ++u) {
                     strip_store(rys[u], xs[u], bn_act_pack(a0[u], a1[u]));
                 }
             } else {
 #pragma unroll
-                for (int u = 0; u < SD_UNROLL; ++u) {
+                for (int u = 0; u < SD_GEN_UNROLL; ++u) {
                     u32x4 packed = u32x4{0u, 0u, 0u, 0u};     // c0 rows outside the image are the conv's zero padding
                     if (!(rys[u] & 4)) {
-                        stem_gather<true, false, IMG>(img_n, ys[u], xs[u], S, S, g, v[u]);
+                        edge_load(n, ys[u], xs[u], v[u]);
                         u32x4 xf;
                         E::store_chunk(&xf, v[u]);
                         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -227,6 +329,18 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
         const int64_t byte0 = (((int64_t)n2 * S + (ho2 == 0 ? 0 : 2 * ho2 + 1)) * S * 3) * (int64_t)sizeof(IMG);
         if (byte0 + SD_WAVES * 1024 < (int64_t)0x7fffffff)
             buffer_load16_lds(rs_img, lds_s + 3 * 2 * PW * 64, (int)byte0 + wave * 1024 + lane * 16, 0);
+    }
+
+    // ---- the next output row's first stem tiles into registers (their round trip hides under the conv phase below)
+    have_pre = reg_row(orow_i + 1);
+    if (have_pre) {
+        const int ho2 = ho + 1;                           // (regular rows never start an image: same n)
+#pragma unroll
+        for (int k = 0; k < SD_PRE; ++k) {
+            int xt, y, slot;
+            reg_tile(k, ho2, xt, y, slot);
+            reg_load(n, y, xt, vpre[k]);
+        }
     }
 
     // ---- 3. stride-2 3x3 conv out of LDS.  Wave (wm, wn): pixel fragments wm, wm+8, ... x channel fragments
@@ -255,10 +369,18 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
                 Mma<DT>::run(acc[f][1], wf[1], xf);
             }
         }
+#if SD_TAPBAR
+        // the preloaded stem tiles stay in registers across this loop: keep the scheduler from pulling several taps' fragment reads
+        // forward (it would spill -- and a spill of a register that a load is still filling waits for that load, here)
+        if (t % SD_TAPBAR == SD_TAPBAR - 1) __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 
     SD_POINT(3);                          // conv 1 MFMAs issued
     // ---- 4. BN + activation; the lane holds channels g*16 + wn*8 + (0..7) of its pixel -> one 16-byte store
+    float sc1[8], sh1[8];
+    read_aff8(lds_aff + 64 + g * 16 + wn * 8, sc1);
+    read_aff8(lds_aff + 128 + g * 16 + wn * 8, sh1);
     const float* sc = sc1; const float* sh = sh1;
     T* const orow = (T*)p.out + ((int64_t)(n * Wo + ho) * Wo) * p.out_cstride + p.out_coff + g * 16 + wn * 8;
 #pragma unroll
@@ -294,7 +416,7 @@ namespace y4 {
 #endif
 
 // c1 weights + c0 ring + the prefetch's scratch KB
-size_t stem_down_lds_bytes(int S) { return (size_t)9 * 64 * 64 + (size_t)3 * 2 * (S / 2 + 1) * 64 + 1024; }
+size_t stem_down_lds_bytes(int S) { return (size_t)9 * 64 * 64 + (size_t)3 * 2 * (S / 2 + 1) * 64 + 1024 + 1024; }
 
 bool stem_down_supported(int dtype, int S) {
     return dtype != Y4_F32 && S % 32 == 0 && stem_down_lds_bytes(S) <= 160 * 1024 && (S / 32 + SD_WM - 1) / SD_WM <= 3;
@@ -340,7 +462,8 @@ int stem_down_launch(int dtype, const void* imgs, int img_u8, int n, int S, cons
     Y4_REQUIRE(stem_down_supported(dtype, S), Y4_EINVAL, "stem_down: dtype %d / image side %d not supported", dtype, S);
     Y4_REQUIRE(imgs && stem_wk && w1_packed && out, Y4_EINVAL, "stem_down: null pointer");
     Y4_REQUIRE(act0 == Y4_ACT_LEAKY && act1 == Y4_ACT_LEAKY, Y4_EINVAL, "stem_down: both convs are LeakyReLU in the plan (got %d, %d)", act0, act1);
-    Y4_REQUIRE((int64_t)n * S * S * 3 < (1ll << 31), Y4_EINVAL, "stem_down: image batch too large");
+    // (the kernel addresses the image batch through one buffer descriptor with 32-bit byte offsets)
+    Y4_REQUIRE((int64_t)n * S * S * 3 * (img_u8 ? 1 : 4) < (1ll << 32), Y4_EINVAL, "stem_down: image batch too large (>= 4 GiB)");
     Y4_REQUIRE(out_cstride % 8 == 0 && out_coff % 8 == 0, Y4_EINVAL, "stem_down: output view not 16-byte aligned");
     StemDownK k{};
     k.img = imgs;
