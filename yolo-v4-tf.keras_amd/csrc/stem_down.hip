@@ -48,8 +48,11 @@ constexpr int SD_UNROLL = 4;                            // stem tiles whose gath
 #define SD_TAPBAR 1
 #endif
 #ifndef SD_PRE_TILES
-#define SD_PRE_TILES 2
+#define SD_PRE_TILES 1
 #endif
+// (measured, same box, 608^2 batch 32, us per launch: no preload 302 | 3 tiles 268 | 2 tiles 259-262, 241 | 1 tile 234.5 against 241: what
+//  pays is that NO wave starts its stem phase by waiting -- one tile is there, the other four are requested at once and land while
+//  it is converted and multiplied -- and more tiles held across the conv phase only cost that phase registers)
 constexpr int SD_PRE = SD_PRE_TILES;                    // preloaded stem tiles per wave (8 registers each across the conv phase)
 // the generic stem loop then serves only the rows that are NOT regular (the first row of a band or image, the last of an image:
 // ~2 % of the rows): two tiles in flight instead of four keep its register peak below what the preloaded tiles leave free
