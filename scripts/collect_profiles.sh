@@ -1,8 +1,8 @@
 #!/bin/bash
-# Collects the measurement set committed under profiles/r03 (run on the GPU box, from the repo root), ONCE per round:
-#   rm -rf gpurun_out/r3set                 # LOCALLY first: gpurun merges into gpurun_out/
-#   gpurun --timeout 2700 -- 'bash scripts/collect_profiles.sh'
-# Produces in gpurun_out/r3set (all from ONE call on one box):
+# Collects the measurement set committed under profiles/r04 (run on the GPU box, from the repo root), ONCE per round:
+#   rm -rf gpurun_out/r4set                 # LOCALLY first: gpurun merges into gpurun_out/
+#   gpurun --timeout 2700 -- 'Y4_COLLECT_TILES=yolo-v4-tf.keras_amd/yolo4hip/schedules/608_80_32_bf16.json bash scripts/collect_profiles.sh'
+# Produces in gpurun_out/r4set (all from ONE call on one box):
 #   bench.json + tiles.json        the default bench (two batches in flight; incl. cpu_baseline) and its tuned tile / fusion set
 #   bench_single_stream.json       the same tile set with --in-flight 1 (HIP events inside the timed blocks)
 #   in_flight_sweep.txt            scripts/two_batches.py 1 / 2 / 3
@@ -15,7 +15,7 @@
 #   bench_cfg5.json / bench_cfg2.json   BASELINE.json configs 5 and 2
 set -x
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3set; rm -rf $O; mkdir -p $O/pmc
+O=gpurun_out/r4set; rm -rf $O; mkdir -p $O/pmc
 SMI="rocm-smi --showclocks --showpower --showtemp --showperflevel --showmaxpower"
 $SMI > $O/smi_idle.txt 2>&1
 # the schedule of the whole set: $Y4_COLLECT_TILES (a schedule file, e.g. scripts/instep_select.py's) if given, else a fresh autotune on THIS box;
@@ -23,14 +23,14 @@ $SMI > $O/smi_idle.txt 2>&1
 if [ -n "$Y4_COLLECT_TILES" ]; then cp "$Y4_COLLECT_TILES" $O/tiles.json; python bench.py --load-tiles $O/tiles.json > $O/bench.json 2> $O/bench.err
 else python bench.py --retune --save-tiles $O/tiles.json > $O/bench.json 2> $O/bench.err; fi
 # steady single-stream load for ~45 s; the sampler starts once the engine is up and the steps are running
-python bench.py --no-cpu-baseline --load-tiles $O/tiles.json --in-flight 1 --steps 1500 --blocks 5 > $O/bench_single_stream.json 2> $O/bench_single_stream.err &
+python bench.py --no-cpu-baseline --no-latency --load-tiles $O/tiles.json --in-flight 1 --steps 1500 --blocks 5 > $O/bench_single_stream.json 2> $O/bench_single_stream.err &
 BPID=$!
 sleep 22
 ( for i in $(seq 1 24); do echo "== sample $i $(date +%s.%N)"; rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|mclk|Power \(W\)|junction"; sleep 0.4; done ) > $O/smi_load.txt 2>&1
 wait $BPID
 for s in 1 2 3; do python scripts/two_batches.py $s 2>/dev/null | tail -1; done > $O/in_flight_sweep.txt
-B1="python3 bench.py --no-cpu-baseline --load-tiles $O/tiles.json --blocks 1 --in-flight 1"
-B2="python3 bench.py --no-cpu-baseline --load-tiles $O/tiles.json --blocks 1"
+B1="python3 bench.py --no-cpu-baseline --no-latency --stop-after-conv -1 --load-tiles $O/tiles.json --blocks 1 --in-flight 1"
+B2="python3 bench.py --no-cpu-baseline --no-latency --stop-after-conv -1 --load-tiles $O/tiles.json --blocks 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B1 --steps 5 --warmup 2 > $O/stats_bench.json 2> $O/stats.err
 python scripts/trace_gaps.py $(ls $O/stats/*/*kernel_trace.csv | head -1) $O/gaps.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- $B2 --steps 6 --warmup 2 > $O/stats2_bench.json 2> $O/stats2.err
@@ -46,8 +46,13 @@ done
 python scripts/pmc_summary.py 4 $O/hbm_traffic.json $O/pmc/pass1 $O/pmc/pass2
 python scripts/pmc_kernels.py $O/pmc_kernels.json $O/pmc/pass3 $O/pmc/pass4 $O/pmc/pass5 > $O/pmc_kernels.txt
 python scripts/mfma_util.py $O/pmc_kernels.json - $O/mfma_util.json $O/sq_wait_breakdown.json > $O/mfma_util.txt
-python bench.py --size 416 --classes 3 --batch 64 --dtype f16 --no-cpu-baseline > $O/bench_cfg5.json 2>/dev/null
-python bench.py --batch 1 --dtype f32 --no-cpu-baseline --steps 50 > $O/bench_cfg2.json 2>/dev/null
+python bench.py --size 416 --classes 3 --batch 64 --dtype f16 --no-cpu-baseline --no-latency > $O/bench_cfg5.json 2>/dev/null
+python bench.py --batch 1 --dtype f32 --no-cpu-baseline --no-latency --steps 50 > $O/bench_cfg2.json 2>/dev/null
+# round 4: the microbenchmark and the in-kernel traces behind DESIGN.md sections 4.0a / 4.2a, and the part-tile A/B of section 4.1c
+scratch/ubench/mish_mfma > $O/ubench_mish_mfma.txt 2>&1
+[ -f scratch/libyolo4hip_cstr_all.so ] && YOLO4HIP_LIB=scratch/libyolo4hip_cstr_all.so python scripts/stage_trace.py > $O/stage_trace.txt 2>&1
+[ -f scratch/libyolo4hip_sdtr2.so ] && YOLO4HIP_LIB=scratch/libyolo4hip_sdtr2.so python scripts/stem_trace.py > $O/stem_trace.txt 2>&1
+for v in 0 1 0 1; do Y4_RB_PARTS=$v python bench.py --no-cpu-baseline --no-latency --in-flight 1 --load-tiles $O/tiles.json --steps 60 --blocks 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('Y4_RB_PARTS=$v one stream', d['value'], 'img/s, conv family', d['roofline']['kernel_ms_per_step'], 'ms, backbone', d['roofline']['backbone_wall']['one_stream'])"; done > $O/resblock_parts.txt 2>&1
 find $O -name "*.csv" -size +20M -delete
 find $O -name "*agent_info.csv" -delete
 ls -la $O $O/stats/* | head -40
