@@ -33,8 +33,19 @@ struct StemDownK {
     unsigned w1_bytes;
 };
 
-constexpr int SD_WAVES = 16, SD_WM = 8, SD_WN = 2;      // 1024 threads: the block is alone on its CU (LDS), so it
-                                                        // brings its own latency hiding
+#ifndef SD_W8
+// Experiment switch, measured SLOWER and off: 1 = EIGHT waves (4 pixel rows x 2 channel halves) with conv 1's weights in REGISTERS
+// (72 per wave; a 512-thread workgroup may use 256) instead of sixteen waves that re-read their 18 weight fragments from LDS for
+// every output row -- the conv phase is bound by its LDS reads (720 ds_read_b128 per row = 5.8 k of its ~7 k cycles, in-kernel
+// trace), and this halves them.  Result (same box, 608^2 batch 32): 321 us against 289-291; 416^2 batch 64 fp16: 317 against 257.
+// With two waves per SIMD the stem phase takes 7-8 k cycles instead of 2.3-4.5 k: a wave issues one VALU instruction per ~9
+// cycles at most, so two waves cannot fill the vector pipe through their own stalls, and the conv phase (5.4-6.7 k) gains nothing
+// because the MFMAs of ten waves' worth of fragments now queue behind two waves' issue.  Bit-identical either way.
+#define SD_W8 0
+#endif
+constexpr int SD_WAVES = SD_W8 ? 8 : 16, SD_WM = SD_W8 ? 4 : 8, SD_WN = 2;      // the block is alone on its CU (LDS), so it
+                                                                                // brings its own latency hiding
+constexpr int SD_LDS_W = SD_W8 ? 0 : 9 * 64 * 64;       // conv 1's weights in LDS: [9 taps][64 rows][64 B] (sixteen-wave form only)
 constexpr int SD_UNROLL = 4;                            // stem tiles whose gathers are in flight together
 #ifndef SD_PRELOAD
 // 1: on a "regular" output row (two new conv-0 rows, every patch inside the image) a wave's first SD_PRE stem tiles are loaded
@@ -83,8 +94,8 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = p.S, Wo = S >> 1, PW = Wo + 1;
     const int MF = Wo >> 4;                                   // pixel fragments per output row
-    char* const lds_w = smem;                                 // [9 taps][64 rows][64 B]
-    char* const lds_s = smem + 9 * 64 * 64;                   // [3 rows][2 planes][PW slots][64 B]
+    char* const lds_w = smem;                                 // [9 taps][64 rows][64 B] (SD_W8 = 0)
+    char* const lds_s = smem + SD_LDS_W;                      // [3 rows][2 planes][PW slots][64 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane & 15, g = lane >> 4;
     // this workgroup's band of output rows (row index = n * Wo + ho)
@@ -92,8 +103,21 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
     const int r_begin = blockIdx.x * per, r_end = min(r_begin + per, rows_total);
     if (r_begin >= r_end) return;
 
-    // ---- 1. c1 weights -> LDS.  LDS row (tap*64 + pr), pr = jn*16 + i, holds channel g'*16 + jn*4 + r'
-    //         (i = g'*4 + r'), so that a lane's 16 accumulator values are 16 consecutive channels.
+    const int wm = wave % SD_WM, wn = wave / SD_WM;
+    // ---- 1. c1 weights.  A lane's 16 accumulator values are 16 consecutive channels: MFMA row i = g'*4 + r' of channel fragment
+    //         jn holds channel g'*16 + jn*4 + r'.
+#if SD_W8
+    //         Into registers, once: fragment (tap t, channel fragment wn*2 + j) = 8 input channels 8g.. of this lane's row
+    u32x4 wreg[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ch = (q >> 2) * 16 + (wn * 2 + j) * 4 + (q & 3);
+            wreg[t][j] = *(const u32x4*)(p.w1 + ((ch * 9 + t) * 32 + g * 8) * 2);
+        }
+#else
+    //         Into LDS: row (tap*64 + pr), pr = jn*16 + i.
     {
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.w1, p.w1_bytes);
         for (int u = wave; u < 9 * 4; u += SD_WAVES) {        // unit = 16 rows = 1024 B = one wave-wide load
@@ -105,6 +129,7 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
             buffer_load16_lds(rs, lds_w + __builtin_amdgcn_readfirstlane(u * 1024), voff, 0);
         }
     }
+#endif
 
     if (tid < 3 * 4) {                                        // the zero column left of the image, once for the three slots
         const int row = ((tid >> 2) * 2 + 1) * PW;
@@ -113,7 +138,6 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
     const int64_t img_bytes = (int64_t)p.N * S * S * 3 * (int64_t)sizeof(IMG);
     const __amdgpu_buffer_rsrc_t rs_img = make_rsrc(p.img, img_bytes < 0xffffffffll ? (unsigned)img_bytes : 0xffffffffu);
     const u32x4 wf0 = p.stem_frag[lane], wf1 = p.stem_frag[64 + lane];
-    const int wm = wave % SD_WM, wn = wave / SD_WM;
     // BN scale / shift of both convs live in LDS ([scale0 32 | shift0 32 | scale1 64 | shift1 64] floats behind the prefetch scratch)
     // and are read where they are used, once per output row: 32 registers that are not held across the other conv's phase
     float* const lds_aff = (float*)(lds_s + 3 * 2 * PW * 64 + 1024);
@@ -196,13 +220,13 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
         // of row y+g-1's run, group 3 float 8 of the three runs -- is sd_lane_off above)
         // a regular row's first tiles were loaded into `vpre` before the previous row's conv phase (have_pre was decided there)
         if (have_pre) {
-            constexpr int NB = 5 - SD_PRE;              // tiles behind the preloaded ones (S <= 640: at most 5 per wave)
-            const bool has_b = wave + SD_WAVES * SD_PRE < sd_nt;      // wave-uniform
+            // a wave's tiles: wave + SD_WAVES k < 2 (S / 16); S / 32 <= 16 MFW * ... / SD_WM fragments per wave row bound them by 2 MFW
+            constexpr int NB = 2 * MFW - SD_PRE;        // tiles behind the preloaded ones
             float vb[NB][8];
             int xtb[NB], yb[NB], slb[NB];
-            if (has_b) {
 #pragma unroll
-                for (int k = 0; k < NB; ++k) {
+            for (int k = 0; k < NB; ++k) {
+                if (wave + SD_WAVES * (SD_PRE + k) < sd_nt) {         // wave-uniform
                     reg_tile(SD_PRE + k, ho, xtb[k], yb[k], slb[k]);
                     reg_load(n, yb[k], xtb[k], vb[k]);
                 }
@@ -236,10 +260,9 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
             };
 #pragma unroll
             for (int k = 0; k < SD_PRE; ++k) finish(vpre[k], xta[k], sla[k]);
-            if (has_b) {
 #pragma unroll
-                for (int k = 0; k < NB; ++k) finish(vb[k], xtb[k], slb[k]);
-            }
+            for (int k = 0; k < NB; ++k)
+                if (wave + SD_WAVES * (SD_PRE + k) < sd_nt) finish(vb[k], xtb[k], slb[k]);
         } else
         for (int t0 = wave; t0 < ntiles; t0 += SD_WAVES * SD_GEN_UNROLL) {
             float v[SD_GEN_UNROLL][8];
@@ -330,8 +353,10 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
     if (orow_i + 1 < r_end) {
         const int n2 = (orow_i + 1) / Wo, ho2 = orow_i + 1 - n2 * Wo;
         const int64_t byte0 = (((int64_t)n2 * S + (ho2 == 0 ? 0 : 2 * ho2 + 1)) * S * 3) * (int64_t)sizeof(IMG);
-        if (byte0 + SD_WAVES * 1024 < (int64_t)0x7fffffff)
-            buffer_load16_lds(rs_img, lds_s + 3 * 2 * PW * 64, (int)byte0 + wave * 1024 + lane * 16, 0);
+        if (byte0 + 16 * 1024 < (int64_t)0x7fffffff)
+#pragma unroll
+            for (int k = 0; k < 16 / SD_WAVES; ++k)
+                buffer_load16_lds(rs_img, lds_s + 3 * 2 * PW * 64, (int)byte0 + (wave + SD_WAVES * k) * 1024 + lane * 16, 0);
     }
 
     // ---- the next output row's first stem tiles into registers (their round trip hides under the conv phase below)
@@ -357,8 +382,12 @@ __global__ __launch_bounds__(64 * SD_WAVES) void stem_down_kernel(const StemDown
         u32x4 wf[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+#if SD_W8
+            wf[j] = wreg[t][j];
+#else
             const int row = t * 64 + (wn * 2 + j) * 16 + q;
             wf[j] = *(const u32x4*)(lds_w + row * 64 + ((g ^ sd_swz(row)) * 16));
+#endif
         }
         // input column 2wo + kx - 1: kx = 0 -> odd plane slot wo, kx = 1 -> even plane slot wo, kx = 2 -> odd plane slot wo+1
         const int row0 = (((2 * ho + ky) % 3) * 2 + (kx == 1 ? 0 : 1)) * PW + (kx == 2 ? 1 : 0) + q;     // ring slot of c0 row 2ho-1+ky
@@ -419,10 +448,10 @@ namespace y4 {
 #endif
 
 // c1 weights + c0 ring + the prefetch's scratch KB
-size_t stem_down_lds_bytes(int S) { return (size_t)9 * 64 * 64 + (size_t)3 * 2 * (S / 2 + 1) * 64 + 1024 + 1024; }
+size_t stem_down_lds_bytes(int S) { return (size_t)SD_LDS_W + (size_t)3 * 2 * (S / 2 + 1) * 64 + 1024 + 1024; }
 
 bool stem_down_supported(int dtype, int S) {
-    return dtype != Y4_F32 && S % 32 == 0 && stem_down_lds_bytes(S) <= 160 * 1024 && (S / 32 + SD_WM - 1) / SD_WM <= 3;
+    return dtype != Y4_F32 && S % 32 == 0 && stem_down_lds_bytes(S) <= 160 * 1024 && (S / 32 + SD_WM - 1) / SD_WM <= (SD_W8 ? 5 : 3);
 }
 
 template <int DT, class IMG>
@@ -453,6 +482,9 @@ static int stem_down_dispatch(const StemDownK& k, hipStream_t stream) {
     }
     switch (mfw) {
         Y4_SD_CASE(1) Y4_SD_CASE(2) Y4_SD_CASE(3)
+#if SD_W8
+        Y4_SD_CASE(4) Y4_SD_CASE(5)
+#endif
         default: set_error("stem_down: image side %d not supported", k.S); return Y4_EINVAL;
     }
     Y4_CHECK_HIP(hipGetLastError());
