@@ -252,6 +252,9 @@ def parse_args(argv):
                     help="activation buffers with disjoint lifetimes share memory (y4_set_workspace_aliasing): 8.0 -> 2.9 GB "
                          "per batch in flight at the headline shape, same bits, +1 %% single-stream")
     ap.add_argument("--per-op", action="store_true", help="also print the per-op time table to stderr")
+    ap.add_argument("--first-image", type=int, default=0,
+                    help="global index of this run's first synthetic image (image i depends on (seed, i) only: a one-process run "
+                         "with --first-image 32 computes what rank 1 of a two-rank run computes)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / protocol self-test on CPU (gloo, no engine, no GPU work): the line says so")
     return ap.parse_args(argv)
@@ -326,6 +329,13 @@ def main():
     rank, local_rank, world = D.init_process_group()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # one process per GPU: rank r of the node drives cuda:{LOCAL_RANK}.  Test hook (tests/test_gpu_dist.py, a box with ONE GPU):
+    # Y4_SHARE_GPU=1 lets every rank use cuda:0 (with Y4_DIST_BACKEND=gloo: RCCL refuses two ranks on one device) so that the
+    # N > 1 path -- shard ranges, the broadcast of the packed weights into a second process, adopt, the reductions -- runs with
+    # real engines; the line then says so
+    shared_gpu = os.environ.get("Y4_SHARE_GPU") == "1"
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if shared_gpu else local_rank
+    local_rank = dev_index
     torch.cuda.set_device(local_rank)
     cfg = make_config(args.size)
     plan = build_plan(args.size, args.classes)
@@ -351,6 +361,7 @@ def main():
         eng.close()
         eng = eng2
     lo, hi = D.shard_range(args.batch * world, rank, world)    # this rank's slice of the global batch
+    lo, hi = lo + args.first_image, hi + args.first_image
     imgs = torch.from_numpy(W.synth_images(hi - lo, args.size, seed=0, first_index=lo)).to(eng.device)
     flat, outs = eng.alloc_outputs_flat(hi - lo)               # five outputs in one block: ONE D2H copy per step
     host = torch.empty(flat.numel(), dtype=torch.int32).pin_memory()
@@ -494,6 +505,7 @@ def main():
     # every rank's own median block (a straggler must be visible the first time this runs on a real node)
     my_ms = statistics.median(own) / args.steps * 1e3
     rank_ms = [float(v) for v in D.gather_objects(my_ms)]
+    rank_digests = D.gather_objects(digest)                  # every rank's outputs of its last step (its own shard of the batch)
 
     if rank == 0:
         dt = statistics.median(blocks)
@@ -533,6 +545,8 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "sharding": f"batch split over {world} rank(s), no data-path collective"},
             "outputs_sha256": digest,
+            "rank_outputs_sha256": rank_digests if world > 1 else None,
+            "first_image": lo,
             "blocks_ms_per_step": [round(b / args.steps * 1e3, 4) for b in blocks],
             "rank_ms_per_step": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4),
                                  "per_rank": [round(v, 4) for v in rank_ms],

@@ -22,14 +22,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_child(extra_env, size=160, classes=3, batch=4):
+def _run_child(extra_env, size=160, classes=3, batch=4, ranks=1, extra_args=()):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.update(extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--blocks", "1",
-           "--warmup", "1", "--no-cpu-baseline", "--no-autotune", "--size", str(size), "--classes", str(classes),
-           "--batch", str(batch)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--blocks", "1",
+           "--warmup", "1", "--no-cpu-baseline", "--no-latency", "--no-autotune", "--size", str(size), "--classes", str(classes),
+           "--batch", str(batch)] + list(extra_args)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -52,3 +52,21 @@ def test_headline_shape_under_torchrun():
     line = _run_child({}, size=608, classes=80, batch=32)
     assert line["n_gpus"] == 1 and line["config"]["global_batch"] == 32 and line["dtype"] == "bf16"
     assert 0.05 < line["roofline"]["frac"] < 1.0 and line["roofline"]["backbone_frac"] and line["roofline"]["end_to_end_frac"]
+
+
+def test_two_ranks_with_real_engines_on_one_gpu():
+    """N = 2 with REAL engines, as far as a box with one GPU allows: two processes share cuda:0
+    (Y4_SHARE_GPU=1; gloo carries the collectives because RCCL refuses two ranks on one device).  Rank 0 packs the weights, the
+    packed workspace is broadcast INTO THE OTHER PROCESS, which adopts it (y4_adopt_packed_weights) and computes images
+    [batch, 2 batch) of the global batch while rank 0 computes [0, batch): each rank's outputs must be bit-identical to what a
+    single process computes for the same global image indices, `value` counts both shards, every rank reports its own time."""
+    share = {"Y4_SHARE_GPU": "1", "Y4_DIST_BACKEND": "gloo"}
+    two = _run_child(share, ranks=2)
+    assert two["n_gpus"] == 2 and two["config"]["global_batch"] == 8 and "2 rank(s)" in two["config"]["sharding"]
+    assert len(two["rank_ms_per_step"]["per_rank"]) == 2 and len(two["rank_outputs_sha256"]) == 2
+    assert two["rank_outputs_sha256"][0] == two["outputs_sha256"] != two["rank_outputs_sha256"][1]
+    first = _run_child({})                                       # one process, images 0..3
+    second = _run_child({}, extra_args=["--first-image", "4"])    # one process, images 4..7
+    assert first["outputs_sha256"] == two["rank_outputs_sha256"][0]
+    assert second["outputs_sha256"] == two["rank_outputs_sha256"][1], "rank 1 (adopted weights, its own shard) differs from one process"
+    assert second["first_image"] == 4

@@ -29,8 +29,9 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("Y4_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
+            assert local_rank < torch.cuda.device_count(), f"LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s)"
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                     device_id=torch.device(f"cuda:{local_rank}"))
@@ -51,7 +52,12 @@ def broadcast_bytes(buf, src=0):
     """Broadcast a uint8 tensor in place (the packed weight workspace)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        dist.broadcast(buf, src=src)
+        if dist.get_backend() != "nccl" and buf.is_cuda:       # gloo (tests: two ranks on one GPU): through the host
+            tmp = buf.cpu()
+            dist.broadcast(tmp, src=src)
+            buf.copy_(tmp)
+        else:
+            dist.broadcast(buf, src=src)
     return buf
 
 
