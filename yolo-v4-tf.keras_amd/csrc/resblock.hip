@@ -27,6 +27,22 @@
 
 namespace y4 {
 
+#ifdef RB_TRACE
+// In-kernel phase trace (kernel experiments only; scripts/res_trace.py): workgroup RB_TR_WG of the FULL-tile launch records s_memtime
+// per wave at fixed points of its tiles RB_TR_T0 .. +2 into rb_trace_buf[tile][wave][point]; y4_rb_trace_read() copies it out.
+__device__ unsigned long long rb_trace_buf[3 * 8 * 16];
+#define RB_TR_WG 8
+#define RB_TR_T0 1
+#define RB_POINT(P)                                                                                         \
+    do {                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (tr_on) asm volatile("s_memtime %0" : "=s"(tr_t[P]));                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    } while (0)
+#else
+#define RB_POINT(P)
+#endif
+
 constexpr int RB_ACT = (RB_ABL & 2) ? Y4_ACT_LEAKY : Y4_ACT_MISH;
 constexpr int RB_T = 16, RB_H = RB_T + 2, RB_WAVES = 8;
 
@@ -140,10 +156,19 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
     };
     if (t < t_hi) { load_x(t); stage_w(0); stage_w(1); stage_w(2); }
 
+#ifdef RB_TRACE
+    int tr_i = 0;
+    unsigned long long tr_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (; t < t_hi; t += nb_x) {
         int n, y_out0, tx;
         locate(t, n, y_out0, tx);
+#ifdef RB_TRACE
+        const bool tr_on = TY == RB_T && C == RB_TRACE && blockIdx.x == RB_TR_WG && tr_i >= RB_TR_T0 && tr_i < RB_TR_T0 + 3;
+#endif
+        RB_POINT(0);                           // arrives at the tile barrier
         wait_vmcnt_then_barrier<0>();          // x tile and stream steps 0..2 landed; all waves left the previous tile
+        RB_POINT(1);                           // barrier passed
 
         // ================= phase A: t = Mish(BN(conv1x1(x))) on the halo'd tile, IN PLACE; zero outside the image.
         // 21 pixel fragments (18 rows + 3 fragments holding the two halo columns); a wave takes fragments wave, wave+8,
@@ -207,7 +232,9 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
             else if (wave + RB_WAVES < G::NFA) phase_a(std::integral_constant<int, 2>{});
             else if (wave < G::NFA) phase_a(std::integral_constant<int, 1>{});
         }
+        RB_POINT(2);                           // 1x1 phase done (MFMAs, Mish, in-place stores issued)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        RB_POINT(3);                           // mid barrier passed
 
         // ================= phase C: y = x + Mish(BN(conv3x3(t))): 9 taps x C/64 stream steps, weights through the ring.
         // Software pipelined at MFMA k-step (32-channel) granularity: the fragments of half-step h+1 are read from LDS
@@ -257,9 +284,12 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
                     for (int j = 0; j < 4; ++j)
                         Mma<DT>::run(acc[i][j], wf[buf][j], xf[buf][i]);
             };
+            RB_POINT(4);                           // residual loads + stream steps issued
             read_frags(0, G::P, 0);                                        // step P landed at the top of the tile
 #pragma unroll
             for (int st = G::P; st < G::NSTEPS; ++st) {
+                if (st == G::P + 3 * G::P) RB_POINT(5);                    // taps 0..2 done
+                if (st == G::P + 6 * G::P) RB_POINT(6);                    // taps 3..5 done
                 // sched_barrier: hipcc otherwise re-serialises the pipeline into "read one fragment, wait for it, 4 MFMAs"
                 // (fewer live registers, but every wait exposes the LDS latency); pinned, the 8-12 reads of the next
                 // half-step are all in flight while the 4*MREP MFMAs of this one issue
@@ -285,8 +315,10 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
                 mma(1);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            RB_POINT(7);                           // all taps done
             // every wave is done with the tile and the ring: bring in the next tile under this tile's epilogue
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            RB_POINT(8);                           // end barrier passed
             if (t + nb_x < t_hi) { if (!(RB_ABL & 8)) load_x(t + nb_x); stage_w(0); stage_w(1); stage_w(2); }
             float sc3[16], sh3[16];
 #pragma unroll
@@ -316,8 +348,24 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
                 }
             }
         }
+        RB_POINT(9);                           // next tile's loads issued, epilogue done, stores issued
+#ifdef RB_TRACE
+        if (tr_on && lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) rb_trace_buf[((tr_i - RB_TR_T0) * 8 + wave) * 16 + k] = tr_t[k];
+        }
+        ++tr_i;
+#endif
     }
 }
+
+#ifdef RB_TRACE
+}  // namespace y4
+extern "C" int y4_rb_trace_read(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(y4::rb_trace_buf), sizeof(unsigned long long) * 3 * 8 * 16);
+}
+namespace y4 {
+#endif
 
 // ------------------------------------------------------------------------------------------------ launch
 bool resblock_supported(int dtype, int c) { return dtype != Y4_F32 && (c == 128 || c == 64); }
