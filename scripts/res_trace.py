@@ -30,12 +30,12 @@ lib = ext.load()
 buf = (C.c_ulonglong * (3 * 8 * 16))()
 lib.y4_rb_trace_read.restype = C.c_int
 assert lib.y4_rb_trace_read(buf) == 0, "not an RB_TRACE build"
-raw = np.array(buf[:], dtype=np.int64).reshape(3, 8, 16)[:, :, :10]
-names = ["arrive", "bar0", "1x1", "midbar", "issue", "taps0-2", "taps3-5", "taps6-8", "endbar", "epilogue"]
+raw = np.array(buf[:], dtype=np.int64).reshape(3, 8, 16)[:, :, :11]
+names = ["arrive", "bar0", "1x1", "midbar", "issue", "taps0-2", "taps3-5", "taps6-8", "endbar", "prefetch", "epilogue"]
 t0 = raw[0, :, 0].min()
 print("cycles per tile (wave 0, arrive -> arrive):", [int(raw[k + 1, 0, 0] - raw[k, 0, 0]) for k in range(2)])
 for k in range(3):
     print("tile", 1 + k)
     for w in range(8):
         r = raw[k, w] - t0
-        print("  wave %d: arrive %7d | dt: " % (w, r[0]) + " ".join("%s %5d" % (names[i + 1], r[i + 1] - r[i]) for i in range(9)))
+        print("  wave %d: arrive %7d | dt: " % (w, r[0]) + " ".join("%s %5d" % (names[i + 1], r[i + 1] - r[i]) for i in range(10)))

@@ -110,6 +110,14 @@ template <> struct Mma32<Y4_F32> {     // (never instantiated for real: the fp32
 __device__ __forceinline__ void buffer_load16_lds(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, int soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
 }
+// 16 bytes per lane to / from registers through a descriptor: 32-bit byte offsets, out-of-range lanes read zeros / store nothing
+__device__ __forceinline__ u32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, int voffset) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, 0, 0);
+}
+// AUX: cache policy bits of the instruction (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX = 0> __device__ __forceinline__ void buffer_store16(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voffset) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, 0, AUX);
+}
 // one dword per lane, same addressing: used to TOUCH a cache line (the data lands in an LDS scratch nobody reads)
 __device__ __forceinline__ void buffer_load4_lds(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, int soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 4, voffset, soffset, 0, 0);
@@ -138,6 +146,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 // by construction, not by timing (resblock.hip phase C).
 template <int N> __device__ __forceinline__ void wait_vmcnt_lgkm_then_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// the same for a count that is a compile-time constant only after unrolling (0 <= n <= MAXN)
+template <int MAXN> __device__ __forceinline__ void wait_vmcnt_lgkm_then_barrier_n(int n) {
+    if constexpr (MAXN >= 0) {
+        if (n == MAXN) wait_vmcnt_lgkm_then_barrier<MAXN>();
+        else wait_vmcnt_lgkm_then_barrier_n<MAXN - 1>(n);
+    }
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt_then_barrier() {
     // counted wait for this wave's own LDS-DMA loads, then the workgroup barrier; one asm statement with a

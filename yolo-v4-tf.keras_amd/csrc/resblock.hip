@@ -24,6 +24,25 @@
 #ifndef RB_ABL
 #define RB_ABL 0
 #endif
+#ifndef RB_RES_LDS
+// 1 (2: also C = 64, where it spills at the 128-register cap): the residual is read from the x tile in LDS (a barrier in front of the
+// 1x1 phase, which overwrites the tile in place) instead of a second time from memory.  Same bytes; measured NEUTRAL (r4): the loop's
+// tail gets 1.4 k cycles shorter per tile, but the next tile's x pieces then block their issuers for 5.4 - 9.8 k cycles instead of
+// 2.5 - 4.8 k -- the residual's loads had been evicting the previous epilogue's dirty output lines from L2 under the loop, which the x
+// fills now have to wait for (write-through stores, RB_ST_AUX=17, bring the 2.9 - 5.8 k back; tile 46.3 k cycles against 45.9 k).
+#define RB_RES_LDS 0
+#endif
+#ifndef RB_ST_AUX
+// cache policy bits of the output stores (1 sc0, 2 nt, 16 sc1); 0: write-back.  nt: tile 49.4 k cycles, write-through 46.3 k (see above)
+#define RB_ST_AUX 0
+#endif
+#ifndef RB_LATE
+// 1: the residual's loads are issued four stream steps before the end of the 3x3 loop instead of in front of it (they are needed in
+// the epilogue only), and stream step 3 -- whose ring slot is free from the start -- with steps 0..2 at the tile hand-over instead of
+// behind the mid barrier.  In-kernel trace: the stretch between the mid barrier and the loop was 1.9 k cycles for the older wave of a
+// SIMD and 4.1 k for the younger one (its loads queue behind the partner's), on the tile's critical path.  Bit-identical.
+#define RB_LATE 1
+#endif
 
 namespace y4 {
 
@@ -51,7 +70,7 @@ constexpr int RB_T = 16, RB_H = RB_T + 2, RB_WAVES = 8;
 // batch with fewer tiles than compute units.  Same MFMAs per output pixel in the same order: bit-identical to the full tile.
 template <int C, int TY = RB_T> struct RbGeom {
     static constexpr int HR = TY + 2;                  // halo'd rows of the tile (halo'd width: RB_H)
-    static constexpr int HROWS = (HR * RB_H + 15) / 16 * 16;              // pixel rows of the LDS tile (padded to a fragment)
+    static constexpr int HROWS = HR * RB_H;            // pixel rows of the LDS tile (no fragment reads past the last one)
     static constexpr int NFA = HR + (2 * HR + 15) / 16;                  // pixel fragments of the 1x1 phase: rows + the two halo columns
     static constexpr int CPR = C / 8;                  // 16-byte chunks of data per pixel row of the LDS tile
     // Rows are PADDED by one chunk instead of XOR-swizzled: 16 lanes reading one chunk of 16 consecutive rows then hit 16
@@ -75,6 +94,7 @@ template <int C, int TY = RB_T> struct RbGeom {
     static constexpr int L_AFF = 0, L_RING = AFF_PAD, L_XT = L_RING + RING * STEP_BYTES;
     static constexpr int LDS = L_XT + XT_PIECES * 1024;
     static constexpr int WN = NF / 4, WM = RB_WAVES / WN, MREP = TY / WM;         // wave grid of the 3x3 phase; NREP = 4
+    static_assert(C != 64 || 2 * LDS <= 160 * 1024, "C = 64: two workgroups per compute unit (resblock_dispatch)");
     static_assert(LDS <= 160 * 1024 && MREP >= 1 && MREP * WM == TY && PPW >= 1 && PPW * RB_WAVES * 1024 == STEP_BYTES && NFA <= 3 * RB_WAVES,
                   "resblock geometry");
 };
@@ -84,7 +104,7 @@ struct ResBlockK {
     char* out;                   // y view
     const char* blob;            // RbGeom<C>::BLOB_BYTES (pack_resblock)
     int in_cstride, in_coff, out_cstride, out_coff;
-    unsigned in_bytes;
+    unsigned in_bytes, out_bytes;
     int N, S;
     int tiles_x, tiles_per_img, ntiles;
     int t_begin, t_end;          // this launch's range of PART tiles: part tile u = 16x16 tile u / (16 / TY), rows (u % (16 / TY)) * TY .. + TY
@@ -94,7 +114,6 @@ struct ResBlockK {
 template <int DT, int C, int TY>
 __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kernel(const ResBlockK p) {
     using E = Elem<DT>;
-    using T = typename E::type;
     using G = RbGeom<C, TY>;
     constexpr int PARTS = RB_T / TY;
     constexpr int ROWB = G::ROWB, CPR = G::CPR, NF = G::NF, MREP = G::MREP;
@@ -121,7 +140,7 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
     };
 
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.blob, G::BLOB_BYTES);
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes), rs_out = make_rsrc(p.out, p.out_bytes);
     // the blob (affine tables + both convs' weight streams: every tile streams all of it) -> this XCD's L2, shared out over the
     // workgroups (conv_common.h: weight_touch); the dwords land in the wave's piece of ring slot 0, which its stage_w(0) overwrites
     static_assert(G::PPW >= 1, "every wave must own piece `wave` of ring slot 0 (stage_w(0), k = 0): it is the touch scratch");
@@ -140,21 +159,39 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
         }
     };
     // halo'd tile of x -> XT (out-of-image pixels and the 12 spare rows read as zeros)
+    // The tile is written lane-linearly in 16-byte slots (slot = piece * 64 + lane; a pixel row is CPR data slots + the pad slot), a
+    // wave takes pieces wave, wave + 8, ...: from one piece to the next every lane's slot advances by the same 512, so its (row,
+    // column, chunk) and its byte offset advance by constants plus two carries.  ~15 VALU instructions per piece instead of the ~35
+    // of two divisions by constants and the full offset polynomial: the wave issues one VALU instruction per ~9 cycles, and the
+    // trace priced the 12 pieces of a C=128 tile at 3.3 k cycles of the epilogue they are issued under.
     auto load_x = [&](int tile) {
         int n, yo, tx;
         locate(tile, n, yo, tx);
         const int y0 = yo - 1, x0 = tx * RB_T - 1;
-        for (int u = wave; u < G::XT_PIECES; u += RB_WAVES) {
-            const int slot = u * 64 + lane;                         // 16-byte slot of the padded tile, written lane-linearly
-            const int hp = slot / (CPR + 1), ch = slot - hp * (CPR + 1);
-            const int hy = hp / RB_H, hx = hp - hy * RB_H;
-            const int gy = y0 + hy, gx = x0 + hx;
-            const bool ok = ch < CPR && hp < G::HR * RB_H && (unsigned)gy < (unsigned)p.S && (unsigned)gx < (unsigned)p.S;
-            const int off = (((n * p.S + gy) * p.S + gx) * p.in_cstride + p.in_coff + ch * 8) * 2;
-            buffer_load16_lds(rs_in, XT + __builtin_amdgcn_readfirstlane(u * 1024), ok ? off : (int)0x80000000, 0);
+        constexpr int SPR = CPR + 1, DSLOT = RB_WAVES * 64, DHP = DSLOT / SPR, DCH = DSLOT % SPR, DHY = DHP / RB_H, DHX = DHP % RB_H;
+        static_assert(DCH + SPR - 1 < 2 * SPR && DHX + RB_H < 2 * RB_H, "one carry per step");
+        int slot0 = wave * 64 + lane;
+        asm volatile("" : "+v"(slot0));        // (per tile: hoisted out of the tile loop, the pieces' positions would cost ~3 registers each)
+        const int hp0 = slot0 / SPR;
+        int ch = slot0 - hp0 * SPR, hy = hp0 / RB_H;
+        int hx = hp0 - hy * RB_H;
+        const int pix_b = p.in_cstride * 2, row_b = p.S * pix_b;           // bytes per pixel / per image row of the view
+        int off = (((n * p.S + y0) * p.S + x0) * p.in_cstride + p.in_coff) * 2 + hy * row_b + hx * pix_b + ch * 16;
+        const int d_off = DHY * row_b + DHX * pix_b + DCH * 16, c_ch = pix_b - SPR * 16, c_hx = row_b - RB_H * pix_b;
+#pragma unroll
+        for (int k = 0; k * RB_WAVES < G::XT_PIECES; ++k) {
+            const int u = wave + k * RB_WAVES;
+            if (u < G::XT_PIECES) {                                         // (wave-uniform; false for some waves' last piece only)
+                const bool ok = ch < CPR && hy < G::HR && (unsigned)(y0 + hy) < (unsigned)p.S && (unsigned)(x0 + hx) < (unsigned)p.S;
+                const int off_x = (RB_ABL & 128) ? (off & ~63) + (lane & 3) * 16 : off;      // (timing experiment: 64-byte aligned quads, wrong data)
+                buffer_load16_lds(rs_in, XT + __builtin_amdgcn_readfirstlane(u * 1024), ok ? off_x : (int)0x80000000, 0);
+            }
+            ch += DCH; hx += DHX; hy += DHY; off += d_off;
+            if (ch >= SPR) { ch -= SPR; hx += 1; off += c_ch; }
+            if (hx >= RB_H) { hx -= RB_H; hy += 1; off += c_hx; }
         }
     };
-    if (t < t_hi) { load_x(t); stage_w(0); stage_w(1); stage_w(2); }
+    if (t < t_hi) { load_x(t); stage_w(0); stage_w(1); stage_w(2); if (RB_LATE) stage_w(3); }
 
 #ifdef RB_TRACE
     int tr_i = 0;
@@ -169,6 +206,18 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
         RB_POINT(0);                           // arrives at the tile barrier
         wait_vmcnt_then_barrier<0>();          // x tile and stream steps 0..2 landed; all waves left the previous tile
         RB_POINT(1);                           // barrier passed
+
+        u32x4 res[MREP][2];                    // residual = x at this lane's output pixels / channels
+        constexpr bool RES_LDS = RB_RES_LDS && (C == 128 || RB_RES_LDS > 1);       // (C = 64: at the 128-register cap it would spill)
+        if (RES_LDS) {
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    res[i][c] = *(const u32x4*)(XT + ((wm * MREP + i + 1) * RB_H + q + 1) * ROWB + chunk_channel(wn * 64, c, g) * 2);
+            // every wave has its residual before any wave's 1x1 phase overwrites the tile
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
 
         // ================= phase A: t = Mish(BN(conv1x1(x))) on the halo'd tile, IN PLACE; zero outside the image.
         // 21 pixel fragments (18 rows + 3 fragments holding the two halo columns); a wave takes fragments wave, wave+8,
@@ -242,18 +291,26 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
         // the two halves of a step.  Fully unrolled (taps, slots and wait counts are compile-time).
         {
             // residual = x at this lane's output pixels / channels, straight from memory (its round trip hides under the loop)
-            u32x4 res[MREP][2];
-            int64_t pix[MREP];
-            bool live[MREP];
+            // (through the buffer descriptors: one 32-bit offset per access -- a dead pixel's is out of range, its load reads zeros and
+            // its store is dropped -- instead of 64-bit pointer arithmetic per access)
+            int pix[MREP];
 #pragma unroll
             for (int i = 0; i < MREP; ++i) {
                 const int gy = y_out0 + wm * MREP + i, gx = tx * RB_T + q;
-                live[i] = gy < p.S && gx < p.S;
-                pix[i] = ((int64_t)n * p.S + (live[i] ? gy : 0)) * p.S + (live[i] ? gx : 0);
-                const T* rp = (const T*)p.in + pix[i] * p.in_cstride + p.in_coff;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) res[i][c] = *(const u32x4*)(rp + chunk_channel(wn * 64, c, g));
+                pix[i] = gy < p.S && gx < p.S ? (n * p.S + gy) * p.S + gx : -1;
             }
+            auto load_res = [&]() {
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) {
+                    const int o = pix[i] < 0 ? (int)0x80000000 : (pix[i] * p.in_cstride + p.in_coff) * 2;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) res[i][c] = buffer_load16(rs_in, o + chunk_channel(wn * 64, c, g) * 2);
+                }
+            };
+            if (!RB_LATE && !RES_LDS) load_res();
+            // RB_LATE: the 2 MREP residual loads go out at the top of stream step S0 and stay in flight beside the stream's own loads:
+            // a wave's loads retire in order, so the counted waits of steps S0 .. S0 + 2 allow that many more outstanding
+            constexpr int S0 = G::NSTEPS - 4, RES_LOADS = RES_LDS ? 0 : 2 * MREP;
             f32x4 acc[MREP][4];
 #pragma unroll
             for (int i = 0; i < MREP; ++i)
@@ -261,7 +318,7 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             // stream steps up to P+3 (4 slots: slot 3 is unused so far, slots < P held the 1x1 weights)
 #pragma unroll
-            for (int st = 3; st <= G::P + 3; ++st) stage_w(st);
+            for (int st = RB_LATE ? 4 : 3; st <= G::P + 3; ++st) stage_w(st);
             const char* const xbase = XT + ((wm * MREP) * RB_H + q) * ROWB + g * 16;       // fragment 0, tap (0, 0), chunk g
             u32x4 xf[2][MREP], wf[2][4];
             auto read_frags = [&](int buf, int st, int kk) {              // all arguments are compile-time after unrolling
@@ -290,6 +347,7 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
             for (int st = G::P; st < G::NSTEPS; ++st) {
                 if (st == G::P + 3 * G::P) RB_POINT(5);                    // taps 0..2 done
                 if (st == G::P + 6 * G::P) RB_POINT(6);                    // taps 3..5 done
+                if (RB_LATE && !RES_LDS && st == S0) load_res();
                 // sched_barrier: hipcc otherwise re-serialises the pipeline into "read one fragment, wait for it, 4 MFMAs"
                 // (fewer live registers, but every wait exposes the LDS latency); pinned, the 8-12 reads of the next
                 // half-step are all in flight while the 4*MREP MFMAs of this one issue
@@ -304,10 +362,11 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
                     // so without it "read to the end" would hold by timing only (they have had all of mma(0) to land: free)
                     constexpr int LAST = G::NSTEPS - 1;
                     const int younger = (st + 3 < LAST ? st + 3 : LAST) - (st + 1);
+                    // (st is a compile-time constant after unrolling: one of the variants survives)
+                    const int extra = RB_LATE && st >= S0 && st <= S0 + 2 ? RES_LOADS : 0;
+                    static_assert(S0 > G::P && 2 * G::PPW + RES_LOADS < 64, "window of the residual's loads");
                     if (RB_ABL & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (timing experiment: no barrier)
-                    else if (younger >= 2) wait_vmcnt_lgkm_then_barrier<2 * G::PPW>();
-                    else if (younger == 1) wait_vmcnt_lgkm_then_barrier<G::PPW>();
-                    else wait_vmcnt_lgkm_then_barrier<0>();
+                    else wait_vmcnt_lgkm_then_barrier_n<2 * G::PPW + RES_LOADS>(younger == 0 ? 0 : (younger >= 2 ? 2 : 1) * G::PPW + extra);
                     if (!(RB_ABL & 4) && st + 4 < G::NSTEPS) stage_w(st + 4);
                     read_frags(0, st + 1, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -319,7 +378,18 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
             // every wave is done with the tile and the ring: bring in the next tile under this tile's epilogue
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             RB_POINT(8);                           // end barrier passed
-            if (t + nb_x < t_hi) { if (!(RB_ABL & 8)) load_x(t + nb_x); stage_w(0); stage_w(1); stage_w(2); }
+            if constexpr (RB_LATE && !RES_LDS) {
+            // The residual has landed (the loop's last counted wait was vmcnt(0)), but the compiler does not know: its own wait in
+            // front of the first use would sit behind the next tile's loads issued below and, counted conservatively, hold the
+            // epilogue until most of THOSE have landed too.  Using the registers here puts that wait where it costs nothing.
+#pragma unroll
+                for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) asm volatile("" : "+v"(res[i][c]));
+            }
+            const bool more = t + nb_x < t_hi;
+            if (more) { if (!(RB_ABL & 8)) load_x(t + nb_x); stage_w(0); stage_w(1); stage_w(2); if (RB_LATE) stage_w(3); }
+            RB_POINT(9);                           // next tile's loads issued
             float sc3[16], sh3[16];
 #pragma unroll
             for (int c = 0; c < 2; ++c)
@@ -335,7 +405,7 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
                 float v[16];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bn_act4<true, RB_ACT>(acc[i][j], sc3 + j * 4, sh3 + j * 4, v + j * 4);
-                T* op = (T*)p.out + pix[i] * p.out_cstride + p.out_coff;
+                const int o = pix[i] < 0 ? (int)0x80000000 : (pix[i] * p.out_cstride + p.out_coff) * 2;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     float rv[8];
@@ -344,15 +414,15 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
                     for (int e = 0; e < 8; ++e) v[c * 8 + e] += rv[e];      // residual Add (custom_layers.py:44), after the activation
                     u32x4 pk;
                     E::store_chunk(&pk, v + c * 8);
-                    if (live[i] && (!(RB_ABL & 16) || pk[0] == 0x12345678u)) *(u32x4*)(op + chunk_channel(wn * 64, c, g)) = pk;
+                    if (!(RB_ABL & 16) || pk[0] == 0x12345678u) buffer_store16<RB_ST_AUX>(rs_out, pk, o + chunk_channel(wn * 64, c, g) * 2);
                 }
             }
         }
-        RB_POINT(9);                           // next tile's loads issued, epilogue done, stores issued
+        RB_POINT(10);                          // epilogue done, stores issued
 #ifdef RB_TRACE
         if (tr_on && lane == 0) {
 #pragma unroll
-            for (int k = 0; k < 10; ++k) rb_trace_buf[((tr_i - RB_TR_T0) * 8 + wave) * 16 + k] = tr_t[k];
+            for (int k = 0; k < 11; ++k) rb_trace_buf[((tr_i - RB_TR_T0) * 8 + wave) * 16 + k] = tr_t[k];
         }
         ++tr_i;
 #endif
@@ -437,11 +507,13 @@ int resblock_launch(int dtype, int c, const void* in, int n, int side, int in_cs
     Y4_REQUIRE(in_cstride % 8 == 0 && in_coff % 8 == 0 && out_cstride % 8 == 0 && out_coff % 8 == 0, Y4_EINVAL,
                "resblock: views not 16-byte aligned");
     const int64_t in_bytes = (int64_t)n * side * side * in_cstride * 2;
-    Y4_REQUIRE(in_bytes < (1ll << 31), Y4_EINVAL, "resblock: input (%lld B) exceeds the 2 GiB buffer-descriptor range", (long long)in_bytes);
+    const int64_t out_bytes = (int64_t)n * side * side * out_cstride * 2;
+    Y4_REQUIRE(in_bytes < (1ll << 31) && out_bytes < (1ll << 31), Y4_EINVAL,
+               "resblock: input (%lld B) or output (%lld B) exceeds the 2 GiB buffer-descriptor range", (long long)in_bytes, (long long)out_bytes);
     ResBlockK k{};
     k.in = (const char*)in; k.out = (char*)out; k.blob = (const char*)blob;
     k.in_cstride = in_cstride; k.in_coff = in_coff; k.out_cstride = out_cstride; k.out_coff = out_coff;
-    k.in_bytes = (unsigned)in_bytes;
+    k.in_bytes = (unsigned)in_bytes; k.out_bytes = (unsigned)out_bytes;
     k.N = n; k.S = side;
     k.touch = weight_touch_enabled() ? 1 : 0;
     k.tiles_x = (side + RB_T - 1) / RB_T; k.tiles_per_img = k.tiles_x * k.tiles_x; k.ntiles = n * k.tiles_per_img;
