@@ -35,6 +35,10 @@ struct ConvK {
     int ksize, stride, pad, act, upsample, out_f32;
     int grid_m, grid_n;
     unsigned in_bytes, wt_bytes;   // buffer-descriptor extents (bounds-checked loads)
+    unsigned out_bytes, out2_bytes, res_bytes;         // extents of the output / residual views; fast_epi: all below 2 GiB
+    int fast_epi;
+    unsigned fin_bytes, fin2_bytes;                    // the same for an LDS pair's tail (fast_tail)
+    int fast_tail;
     FastDiv div_howo, div_wo;      // m -> (n, ho, wo) without integer division
     FastDiv div_gridn;
     char* out2;                    // channels >= split go to this view (fused CSP route + main-in pair)
@@ -270,6 +274,72 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[
     }
 }
 
+#ifndef Y4_FAST_EPI
+#define Y4_FAST_EPI 1              // (0: kernel experiments, the general epilogue everywhere)
+#endif
+// The same for the case nearly every tile of a step is: a FULL tile (no row / channel predicates), 16-byte stores of the compute
+// dtype, no 2x2 replication.  Addresses are 32-bit byte offsets into buffer descriptors of the views -- one multiply per pixel row,
+// the chunks' offsets immediates -- where the general path above pays 64-bit pointer arithmetic and a view select per store (its
+// ISA: ~200 VALU instructions per pixel row beside the ~80 of the activation), and the residual rows are loaded two rows ahead of
+// their use instead of in front of it.  Same values, same order of operations on them: bit-identical.
+template <int DT, int MREP, int NREP, int ACT, bool RES, int GW>
+__device__ __forceinline__ void conv_epilogue_fast(const ConvK& p, f32x4 (&acc)[MREP][NREP], const float* sc, const float* sh, int mrow,
+                                                   int chw, int fg) {
+    using E = Elem<DT>;
+    constexpr int EPC = E::EPC, ES = 16 / EPC, NC = NREP / 2, SPC = 8 / EPC;      // SPC: 16-byte stores per 8-channel chunk
+    constexpr bool FAST = (DT != Y4_F32);
+    constexpr int ROWS = 64 / GW, CSTEP = GW * 8 * ES;                             // pixels between fragments, bytes between chunks
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.out, p.out_bytes), rs2 = make_rsrc(p.split > 0 ? p.out2 : p.out, p.split > 0 ? p.out2_bytes : p.out_bytes);
+    // chunks [0, nfirst) go to `out`, the others to `out2` (wave-uniform: split and chw are multiples of 32)
+    const int chw_u = __builtin_amdgcn_readfirstlane(chw);
+    const int nfirst = p.split > 0 ? min(max((p.split - chw_u) / (GW * 8), 0), NC) : NC;
+    const int lane1 = (p.out_coff + chw + fg * 8) * ES, lane2 = (p.out2_coff + chw - p.split + fg * 8) * ES;
+    const int row1 = p.out_cstride * ES, row2 = p.out2_cstride * ES;
+    u32x4 res[RES ? 3 : 1][NC * SPC];
+    const __amdgpu_buffer_rsrc_t rsr = make_rsrc(RES ? p.res : p.out, RES ? p.res_bytes : p.out_bytes);
+    const int laner = (p.res_coff + chw + fg * 8) * ES, rowr = p.res_cstride * ES;
+    auto load_res = [&](int i) {
+        const int o = (mrow + i * ROWS) * rowr + laner;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int h = 0; h < SPC; ++h) res[i % 3][c * SPC + h] = buffer_load16(rsr, o + c * CSTEP + h * 16);
+    };
+    if constexpr (RES) {
+        load_res(0);
+        if (MREP > 1) load_res(1);
+    }
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        if constexpr (RES) {
+            if (i + 2 < MREP) load_res(i + 2);
+        }
+        float v[NC * 8];
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) bn_act4<FAST, ACT>(acc[i][j], sc + j * 4, sh + j * 4, v + j * 4);
+        if constexpr (RES) {
+#pragma unroll
+            for (int k = 0; k < NC * SPC; ++k) {
+                float rv[EPC];
+                E::load_chunk(&res[i % 3][k], rv);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[k * EPC + e] += rv[e];
+            }
+        }
+        const int m = mrow + i * ROWS;
+        const int o1 = m * row1 + lane1, o2 = m * row2 + lane2;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int h = 0; h < SPC; ++h) {
+                u32x4 pk;
+                E::store_chunk(&pk, v + c * 8 + h * EPC);
+                if (c < nfirst) buffer_store16(rs1, pk, o1 + c * CSTEP + h * 16);
+                else buffer_store16(rs2, pk, o2 + c * CSTEP + h * 16);
+            }
+    }
+}
+
 template <int DT, int MREP, int NREP, bool XL = false, int GW = 4>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP][NREP], int mrow, int m_limit, int chw,
                                               int fg, bool full, char* xl = nullptr, int xrow = 0, int xpanel = 0) {
@@ -287,6 +357,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP]
         }
     }
     // the activation and the mask mode are compile-time inside; one uniform switch outside the pixel loop
+    if (Y4_FAST_EPI && !XL && GW == 4 && full && p.fast_epi && p.act != Y4_ACT_LINEAR && (p.act == Y4_ACT_MISH || !p.res)) {
+        if (p.act == Y4_ACT_LEAKY) conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_LEAKY, false, GW>(p, acc, sc, sh, mrow, chw, fg);
+        else if (p.res) conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_MISH, true, GW>(p, acc, sc, sh, mrow, chw, fg);
+        else conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_MISH, false, GW>(p, acc, sc, sh, mrow, chw, fg);
+        return;
+    }
     if (p.act == Y4_ACT_MISH) {
         if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, true, XL, GW>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
         else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_MISH, false, XL, GW>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);

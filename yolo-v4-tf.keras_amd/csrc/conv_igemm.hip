@@ -76,6 +76,12 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
                "conv2d: input (%lld B) or weights (%lld B) exceed the 2 GiB buffer-descriptor range", (long long)in_bytes,
                (long long)wt_bytes);
     k.in_bytes = (unsigned)in_bytes; k.wt_bytes = (unsigned)wt_bytes;
+    {   // extents of the views the fast epilogue addresses through buffer descriptors (conv_common.h: conv_epilogue_fast)
+        const int64_t ob = (int64_t)k.M * d->out_cstride * es, ob2 = d->out2 ? (int64_t)k.M * d->out2_cstride * es : 0,
+                      rb = d->res ? (int64_t)k.M * d->res_cstride * es : 0;
+        k.fast_epi = !d->upsample && !d->out_f32 && ob < (1ll << 31) && ob2 < (1ll << 31) && rb < (1ll << 31);
+        if (k.fast_epi) { k.out_bytes = (unsigned)ob; k.out2_bytes = (unsigned)ob2; k.res_bytes = (unsigned)rb; }
+    }
     k.div_howo = fastdiv_make((uint32_t)(k.Ho * k.Wo)); k.div_wo = fastdiv_make((uint32_t)k.Wo);
     k.in_cstride = d->in_cstride; k.in_coff = d->in_coff;
     k.out_cstride = d->out_cstride; k.out_coff = d->out_coff;
@@ -100,6 +106,9 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
                    Y4_EINVAL, "conv2d: bad LDS-pair split description");
         k.fin2 = (char*)pair->fin2; k.fin2_cstride = pair->fin2_cstride; k.fin2_coff = pair->fin2_coff;
         k.tail_split = pair->fin2 ? pair->split : 0;
+        const int64_t fb = (int64_t)k.M * pair->fin_cstride * es, fb2 = pair->fin2 ? (int64_t)k.M * pair->fin2_cstride * es : 0;
+        k.fast_tail = !pair->out_f32 && fb < (1ll << 31) && fb2 < (1ll << 31);
+        if (k.fast_tail) { k.fin_bytes = (unsigned)fb; k.fin2_bytes = (unsigned)fb2; }
     }
     if (chain && chain->ntail > 0) {
         Y4_REQUIRE(d->dtype != Y4_F32 && d->cout == 64 && d->act == Y4_ACT_MISH && !d->upsample && !d->out_f32 && !d->out2 &&

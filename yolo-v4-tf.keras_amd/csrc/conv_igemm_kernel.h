@@ -511,6 +511,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         p2.out = p.fin; p2.out_cstride = p.fin_cstride; p2.out_coff = p.fin_coff;
         p2.cout_store = p.tail[0].cout; p2.upsample = 0; p2.out_f32 = p.pair >> 1;
         p2.split = p.tail_split; p2.out2 = p.fin2; p2.out2_cstride = p.fin2_cstride; p2.out2_coff = p.fin2_coff;
+        p2.fast_epi = p.fast_tail; p2.out_bytes = p.fin_bytes; p2.out2_bytes = p.fin2_bytes;
         conv_epilogue<DT, MREP, NREP>(p2, acc2, mrow, p.M, chw, fg, (m0 + BM <= p.M) && BN <= p2.cout_store);
         if (p.store_x) pair_store_tile<DT, MREP, NREP>(p, xl, xrow, XPANEL, mrow, p.M, chw, fg);
     } else {
