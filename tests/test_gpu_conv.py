@@ -142,6 +142,54 @@ def test_mfma32_tiles_vs_oracle(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_deep_ring_tiles_short_and_long_k(dtype):
+    """The ring tiles with 3..7 LDS stages (conv_tiles.h; the deep ones are what a single image's latency-bound K loops run on)
+    with FEWER K-tiles than stages (1x1 convs over 64 / 128 / 192 channels at bf16: 1, 2, 3 K-tiles), exactly as many, and many
+    more: bit-identical to the two-stage 64x64 tile (same K order), which is held to the oracle; also as split-K bases."""
+    import ctypes as C
+    from yolo4hip import ext
+    from yolo4hip.weights import ConvWeights
+    lib = ext.load()
+    deep = []
+    for tile in range(1, lib.y4_conv_tile_count() + 1):
+        cfg = (C.c_int32 * 6)()
+        ext.check(lib.y4_conv_tile_desc(tile, cfg))
+        if 3 <= cfg[5] <= 7: deep.append((tile, cfg[5]))
+    assert max(n for _, n in deep) >= 6 and len(deep) >= 6, deep
+    atol, rtol = TOL[dtype]
+    ran = ran_split = 0
+    for (k, cin, cout, side, act, use_res) in [(1, 64, 128, 19, "mish", False), (1, 128, 64, 13, "leaky", False), (1, 192, 128, 19, "mish", True),
+                                                (1, 384, 255, 13, "linear", False), (3, 128, 128, 19, "mish", True), (3, 512, 256, 13, "leaky", False)]:
+        rng = np.random.default_rng(cin + cout + k)
+        x = quantize(rng.standard_normal((1, side, side, cin)).astype(np.float32), dtype)
+        cw = make_conv_weights(rng, cout, cin, k, act != "linear")
+        cwq = ConvWeights(w=quantize(cw.w, dtype), bn=cw.bn, bias=cw.bias)
+        res = quantize(rng.standard_normal((1, side, side, cout)).astype(np.float32), dtype) if use_res else None
+        want = _ref(x, cwq, k, 1, act, res, False)
+        base, _ = run_conv_gpu(x, cwq, k, 1, act, dtype, residual=res, tile=10)
+        d = np.abs(base - want)
+        assert np.all(d <= atol + rtol * np.abs(want)), f"tile 10 {k}x{k} {cin}->{cout}: max err {d.max():.3e}"
+        for tile, nst in deep:
+            try:
+                got, _ = run_conv_gpu(x, cwq, k, 1, act, dtype, residual=res, tile=tile)
+            except ext.Y4Error as err:
+                assert err.code == -22      # (64-byte K rows against this cin, or a tile that is not built for float32)
+                continue
+            assert np.array_equal(got, base), f"tile {tile} ({nst} stages) {k}x{k} {cin}->{cout}: {np.abs(got - base).max()}"
+            ran += 1
+            if nst >= 5:
+                try:
+                    got, _ = run_conv_gpu(x, cwq, k, 1, act, dtype, residual=res, tile=tile + 100)
+                except ext.Y4Error as err:
+                    assert err.code == -22
+                    continue
+                d = np.abs(got - want)
+                assert np.all(d <= atol + rtol * np.abs(want)), f"tile {tile}+100 {k}x{k} {cin}->{cout}: max err {d.max():.3e}"
+                ran_split += 1
+    assert ran >= 30 and ran_split >= 6, (ran, ran_split)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_splitk_tiles_vs_oracle(dtype):
     """Split-K tile ids (base + 100 e: the K loop split 2^e ways, the last split to arrive adds the partial sums and runs the
     epilogue; the latency schedules of batch 1) against the same float64-free reference and tolerance as every other tile --

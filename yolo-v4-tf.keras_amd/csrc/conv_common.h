@@ -164,6 +164,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_then_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// min(k, MAXK) younger stages of UNIT loads each may stay in flight (k: runtime, wave-uniform)
+template <int MAXK, int UNIT> __device__ __forceinline__ void wait_vmcnt_then_barrier_k(int k) {
+    if constexpr (MAXK <= 0) wait_vmcnt_then_barrier<0>();
+    else {
+        if (k >= MAXK) wait_vmcnt_then_barrier<MAXK * UNIT>();
+        else wait_vmcnt_then_barrier_k<MAXK - 1, UNIT>(k);
+    }
+}
+
 
 // ---- channel <-> lane layout of a wave's accumulator tile ("chunked"): within the wave's block of 16*NREP channels
 // starting at `chw`, lane group g = lane>>4 owns, for c = 0 .. NREP/2-1, the 8 channels chw + (4c + g)*8 .. +7:

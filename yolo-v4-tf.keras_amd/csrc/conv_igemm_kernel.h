@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     static_assert(RPI <= BM, "weight_touch scratch must be a piece the same wave's first stage load overwrites");
     static_assert(MREP >= 1 && NREP >= 1, "wave tile");
     constexpr int LPT = A_IT + B_IT;        // LDS-DMA instructions a wave issues per stage
-    static_assert(SN >= 2 && SN <= 4 && (SN == 2 || !B_PART), "deep pipelines need uniform weight loads per wave");
+    static_assert(SN >= 2 && SN <= 7 && (SN == 2 || !B_PART), "deep pipelines need uniform weight loads per wave");
     static_assert((SN - 2) * LPT <= 63, "vmcnt field");
     static_assert(!PHASED || (NT == 512 && KSTEPS == 2), "phased schedule: 8 waves, 128-byte K rows");
     static_assert(!M32 || (DT != Y4_F32 && BKB == 128 && WPX % 32 == 0 && WCH % 32 == 0 && CHAIN == 0 && !PAIR && !B_PART),
@@ -387,18 +387,18 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
             asm volatile("s_barrier" ::: "memory");
         } else
 #endif
-        if (SN == 2 || ahead == 0) wait_vmcnt_then_barrier<0>();
-        else if (a_skip) {                     // this wave issues one load fewer per stage (partial last A iteration)
-            if (SN == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT - 1>();
-            else wait_vmcnt_then_barrier<2 * (LPT - 1)>();
-        } else if (SN == 3 || ahead == 1) wait_vmcnt_then_barrier<LPT>();
-        else wait_vmcnt_then_barrier<2 * LPT>();
+        if (a_skip) wait_vmcnt_then_barrier_k<SN - 2, LPT - 1>(ahead);       // (this wave issues one load fewer per stage: partial last A iteration)
+        else wait_vmcnt_then_barrier_k<SN - 2, LPT>(ahead);
         TR_POINT(1);                           // past the barrier
         if (kt == 0) TR_LIFE(2, "s_memtime");
-        if (kt + SN - 1 < nk) stage(nxt);
+        // deep rings (a single image's latency-bound K loops: 4 MFMAs per wave and K-tile) issue the fragment reads FIRST: the next
+        // stage's loads have five K-tiles of slack, the reads' round trip is on the K-tile's critical path
+        constexpr bool READS_FIRST = SN >= 5;
+        if (!READS_FIRST && kt + SN - 1 < nk) stage(nxt);
         TR_POINT(2);                           // next tile's loads issued (and the staging cursor advanced)
         const char* sx = lds_x + cur * STAGE;
         const char* sw = lds_w + cur * STAGE;
+        const int nxt_now = nxt;
         cur = cur + 1 == SN ? 0 : cur + 1;
         nxt = nxt + 1 == SN ? 0 : nxt + 1;
         if constexpr (PREFRAG) {
@@ -413,6 +413,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
                 for (int j = 0; j < NREP; ++j) wf[kk][j] = *(const u32x4*)(sw + j * 16 * BKB + xo[kk]);
             }
             TR_POINT(3);                       // fragment reads issued
+            if (READS_FIRST && kt + SN - 1 < nk) stage(nxt_now);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk)
@@ -605,7 +606,7 @@ static int launch_plain(int tile, const ConvK& k, hipStream_t s) {
     // the fp32 (parity) path instantiates only the first F32_TILES configurations (build time)
 #define Y4_TILE_CASE(id, bm, bn, wm, wn, bkb, nst)                                            \
     case id:                                                                                  \
-        if constexpr (DT == Y4_F32 && (id > F32_TILES)) break;                                \
+        if constexpr (DT == Y4_F32 && !f32_tile(id)) break;                                   \
         else if constexpr (DT == Y4_F32 && nst == 32) break;                                  \
         else if constexpr (nst == 8 || nst == 9 || nst == 10) return conv_p8_launch(DT, bm, nst, k, s); \
         else return launch_cfg<DT, bm, bn, wm, wn, bkb, nst>(k, s);

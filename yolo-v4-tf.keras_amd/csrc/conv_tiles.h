@@ -7,7 +7,7 @@ namespace y4 {
 struct TileCfg {
     int bm, bn, wm, wn, bkb, nst;
 };
-// id, BM (pixels), BN (channels), WM, WN (wave grid), BKB (bytes of K per LDS row), NST (ring stages; 12 = the staggered
+// id, BM (pixels), BN (channels), WM, WN (wave grid), BKB (bytes of K per LDS row), NST (ring stages, 2..7; 12 = the staggered
 // 2-stage schedule, 32 = 2 stages with the 32x32x16 MFMA; conv_p8_kernel.h: 8 = staggered wave groups, 9 = software-pipelined;
 // 10 = the producer / consumer kernel of conv_l12_kernel.h).
 // The table is also what tests and the autotuner sweep through y4_conv_desc.tile.
@@ -53,13 +53,22 @@ struct TileCfg {
     X(39, 192, 256, 2, 4, 128, 8) \
     X(40, 256, 256, 2, 4, 128, 8) \
     X(41, 192, 256, 2, 4, 128, 9) \
-    X(42, 192, 256, 2, 4, 128, 10)
+    X(42, 192, 256, 2, 4, 128, 10) \
+    X(43, 64, 128, 1, 4, 128, 6)  \
+    X(44, 32, 128, 1, 4, 128, 6)  \
+    X(45, 128, 128, 2, 2, 128, 4) \
+    X(46, 64, 64, 2, 2, 128, 6)   \
+    X(47, 128, 64, 4, 1, 128, 4)  \
+    X(48, 32, 64, 2, 2, 128, 7)
 
 #define Y4_TILE_ROW(id, bm, bn, wm, wn, bkb, nst) {bm, bn, wm, wn, bkb, nst},
 static const TileCfg kTiles[] = {Y4_TILES(Y4_TILE_ROW)};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 constexpr int F32_TILES = 12;
+// ... and the deep rings (round 4: what a single image's latency-bound K loops need)
+constexpr int DEEP_TILE0 = 43;
+inline constexpr bool f32_tile(int id) { return id <= F32_TILES || id >= DEEP_TILE0; }
 
 // the tiles that sum in the 32x32x16 MFMA's order (bit-identical among themselves, not with the others)
 inline bool mfma32_tile(int tile) { return tile >= 1 && tile <= kNumTiles && kTiles[tile - 1].nst == 32; }
@@ -75,7 +84,7 @@ inline bool tuner_skips_tile(int tile) { return mfma32_tile(tile) || (tile >= 1 
 constexpr int SPLITK_MAX_E = 3;
 constexpr int SPLITK_CNT_BYTES = 16 * 1024;          // 4096 tile counters in front of the partial sums
 constexpr size_t SPLITK_WS_BYTES = SPLITK_CNT_BYTES + (size_t)32 * 1024 * 1024;      // what an engine's workspace reserves for it
-inline bool splitk_tile(int base) { return base >= 1 && base <= kNumTiles && kTiles[base - 1].nst >= 2 && kTiles[base - 1].nst <= 4; }
+inline bool splitk_tile(int base) { return base >= 1 && base <= kNumTiles && kTiles[base - 1].nst >= 2 && kTiles[base - 1].nst <= 7; }
 inline int tile_base(int tile) { return tile >= 100 ? tile % 100 : tile; }
 inline int tile_split_e(int tile) { return tile >= 100 ? tile / 100 : 0; }
 // a well-formed tile id (0 = heuristic)
