@@ -349,11 +349,10 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& p, f32x4 (&acc)[
     }
 }
 
-template <int DT, int MREP, int NREP, bool XL = false, int GW = 4>
-__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP][NREP], int mrow, int m_limit, int chw,
-                                              int fg, bool full, char* xl = nullptr, int xrow = 0, int xpanel = 0) {
+// the folded BatchNorm scale / shift of this lane's channels (a wave's block of 16 NREP channels from `chw`)
+template <int NREP, int GW = 4>
+__device__ __forceinline__ void conv_epilogue_tables(const ConvK& p, int chw, int fg, float (&sc)[NREP * 4], float (&sh)[NREP * 4]) {
     constexpr int NC = NREP / 2;
-    float sc[NC * 8], sh[NC * 8];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int ch = chunk_channel_g<GW>(chw, c, fg);
@@ -365,6 +364,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP]
             for (int e = 0; e < 4; ++e) { sc[c * 8 + h + e] = s4[e]; sh[c * 8 + h + e] = h4[e]; }
         }
     }
+}
+
+template <int DT, int MREP, int NREP, bool XL = false, int GW = 4>
+__device__ __forceinline__ void conv_epilogue_with(const ConvK& p, f32x4 (&acc)[MREP][NREP], const float (&sc)[NREP * 4], const float (&sh)[NREP * 4],
+                                                   int mrow, int m_limit, int chw, int fg, bool full, char* xl = nullptr, int xrow = 0,
+                                                   int xpanel = 0) {
     // the activation and the mask mode are compile-time inside; one uniform switch outside the pixel loop
     if (Y4_FAST_EPI && !XL && GW == 4 && full && p.fast_epi && p.act != Y4_ACT_LINEAR && (p.act == Y4_ACT_MISH || !p.res)) {
         if (p.act == Y4_ACT_LEAKY) conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_LEAKY, false, GW>(p, acc, sc, sh, mrow, chw, fg);
@@ -382,6 +387,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP]
         if (full) conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, true, XL, GW>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
         else conv_epilogue_impl<DT, MREP, NREP, Y4_ACT_LINEAR, false, XL, GW>(p, acc, sc, sh, mrow, m_limit, chw, fg, xl, xrow, xpanel);
     }
+}
+
+template <int DT, int MREP, int NREP, bool XL = false, int GW = 4>
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP][NREP], int mrow, int m_limit, int chw,
+                                              int fg, bool full, char* xl = nullptr, int xrow = 0, int xpanel = 0) {
+    float sc[NREP * 4], sh[NREP * 4];
+    conv_epilogue_tables<NREP, GW>(p, chw, fg, sc, sh);
+    conv_epilogue_with<DT, MREP, NREP, XL, GW>(p, acc, sc, sh, mrow, m_limit, chw, fg, full, xl, xrow, xpanel);
 }
 
 // LDS pair: the head conv's tile, kept in LDS by the XL epilogue, goes to its HBM view(s) (lane re-reads the chunks it

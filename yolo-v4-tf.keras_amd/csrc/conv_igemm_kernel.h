@@ -235,6 +235,12 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 #pragma unroll
         for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // small tiles (one chunk pair per lane: 16 registers): the BatchNorm tables' loads go out in front of the K loop instead of in
+    // front of the epilogue, where their round trip is all a short kernel would be waiting for (a single image: ~90 such kernels)
+    constexpr bool EARLY_TABLES = CHAIN == 0 && !PAIR && !M32 && !PHASED && NREP <= 2;
+    float sc_early[NREP * 4], sh_early[NREP * 4];
+    if constexpr (EARLY_TABLES) conv_epilogue_tables<NREP>(p, n0 + wn * WCH, fg, sc_early, sh_early);
+
     TR_LIFE(1, "s_memtime");
     if constexpr (M32) {
         // Same staging, same LDS image, same one-barrier 2-stage loop; the K-tile is 4 k-steps of 16 with 32x32 blocks:
@@ -555,7 +561,8 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
             }
         }
         const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.cout_store);
-        conv_epilogue<DT, MREP, NREP>(p, acc, m0 + wm * WPX + frow, p.M, n0 + wn * WCH, fg, full);
+        if constexpr (EARLY_TABLES) conv_epilogue_with<DT, MREP, NREP>(p, acc, sc_early, sh_early, m0 + wm * WPX + frow, p.M, n0 + wn * WCH, fg, full);
+        else conv_epilogue<DT, MREP, NREP>(p, acc, m0 + wm * WPX + frow, p.M, n0 + wn * WCH, fg, full);
         TR_LIFE(4, "s_memtime");
         TR_LIFE(6, "s_memrealtime");
 #ifdef Y4_TRACE

@@ -14,10 +14,11 @@
 // candidates in that class's own descending order, so the per-class kept sets equal TensorFlow's
 // per-class greedy runs, and the kept boxes come out already in the final descending-score order; the
 // pass stops after max_total kept boxes (a class's 101st kept box can never be in the overall top 100, so
-// max_per_class is enforced with a same-class count).  Candidates are taken in chunks of at most SORT_CAP
-// in descending key order (radix-select of the chunk pivot when an image has more than SORT_CAP
-// candidates), sorted (rank sort up to 1024 keys, register bitonic network above), their boxes gathered into LDS, then
-// scanned by wave 0, 64 candidates at a time (see the greedy pass).
+// max_per_class is enforced with a same-class count).  Candidates are taken in chunks in descending key order
+// (radix-select of the chunk pivot when an image has more than a chunk holds): the first of at most NMS_THREADS keys
+// -- merge-rank sorted, and decided ROUND-PARALLEL, one candidate per thread (round 4; see the greedy pass) --, the
+// later ones, which only an image that has not filled max_total from its best 1024 candidates reaches, of at most
+// SORT_CAP keys through the register bitonic network and wave 0's pass over 64 candidates at a time.
 // IoU is TensorFlow's: corners min/max-normalised, 0 if either area <= 0, suppress iff IoU > threshold.
 #include "kernels.h"
 
@@ -224,7 +225,11 @@ __device__ __forceinline__ void decode_one_cell(const DecodeK& p, const DecodeCe
 // (cell c, anchor a) -- 48 four-byte loads, three 64-byte sectors per cell instead of its 1 KB -- and the ballot of
 // sigmoid(obj) > threshold (the same float32 decision decode_one_cell makes) says which cells can have candidates at all
 // (27 % on the synthetic heads).  Only those are then read in full, one at a time.  HBM bytes per cell 1024 -> ~470.
-constexpr int DC_SCREEN = 16;
+// Round 4: DC_SCREEN is a template parameter -- a few images (the reference's own call is ONE) are 1 421 waves of 16 cells on 1 024
+// SIMDs, each walking its ~4 flagged cells one after the other with nothing beside it to hide the loads; 4 cells per wave are four
+// times the waves with a quarter of the chain (34 -> see DESIGN.md section 4.4).  The candidate lists' order differs, NMS sorts them.
+constexpr int DC_SCREEN = 16, DC_SCREEN_SMALL = 4;
+template <int DC_SCREEN>
 __global__ __launch_bounds__(256) void decode_cell_kernel(const DecodeK p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t cell0 = ((int64_t)blockIdx.x * 4 + wave) * DC_SCREEN, ncell = (int64_t)p.N * p.cells_per_img;
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(256) void decode_cell_kernel(const DecodeK p) {
     const int nf = 5 + p.C, nval = 3 * nf;
     const int c = lane >> 2, a = lane & 3;
     bool pass = false;
-    if (a < 3 && cell0 + c < ncell) {
+    if (a < 3 && c < DC_SCREEN && cell0 + c < ncell) {
         const DecodeCell cl = decode_locate(p, cell0 + c);
         pass = sigmoid_f(cl.src[a * nf + 4]) > p.score_thr;
     }
@@ -265,6 +270,8 @@ __global__ __launch_bounds__(256) void decode_cell_kernel(const DecodeK p) {
 // ------------------------------------------------------------------------------------------- NMS
 constexpr int NMS_THREADS = 1024;
 constexpr int SORT_CAP = 4096;
+constexpr int PAR_MAX_C = 1024;      // class count up to which the round-parallel greedy pass has its per-class LDS words
+constexpr uint32_t PAR_NONE = 0xffffffffu;
 
 __device__ __forceinline__ float iou_tf(const float4 a, const float4 b) {
     const float ay0 = fminf(a.x, a.z), ax0 = fminf(a.y, a.w), ay1 = fmaxf(a.x, a.z), ax1 = fmaxf(a.y, a.w);
@@ -343,7 +350,11 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
     int* kidx = (int*)(kscore + p.max_total);                              // max_total
     uint32_t* hist = (uint32_t*)(kidx + p.max_total);                      // 256
     uint32_t* sh = hist + 256;                                             // scratch words
-    // sh[0]=count in chunk, sh[1]=kept, sh[2]=remaining below cutoff, sh[3..4]=pivot lo/hi, sh[5]=need
+    // sh[0]=count in chunk, sh[1]=kept, sh[2]=remaining below cutoff, sh[3..4]=pivot lo/hi, sh[5]=need;
+    // round-parallel pass: sh[8..9] = lowest undecided position (two alternating buffers), sh[10..11] = kept below it
+    uint32_t* pfirst = sh + 16;                                            // [2][C] lowest undecided position of a class
+    uint32_t* pcount = pfirst + 2 * (p.C <= PAR_MAX_C ? p.C : 0);          // [C] kept boxes of a class
+    uint32_t* pflag = pcount + (p.C <= PAR_MAX_C ? p.C : 0);               // [NMS_THREADS] candidate was kept; then [16] per-wave kept counts
 
     const int n = blockIdx.x, tid = threadIdx.x;
     uint32_t cnt = p.counts[(size_t)n * COUNT_STRIDE];
@@ -373,11 +384,51 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
         __syncthreads();
         const uint32_t remaining = sh[2];
         if (remaining == 0) break;
-        // ---- pivot = SORT_CAP-th largest key below the cutoff (0 when everything fits)
+        // ---- pivot = chunk_cap-th largest key below the cutoff (0 when everything fits).  The FIRST chunk is at most NMS_THREADS
+        // keys -- what the merge-rank sort and the round-parallel pass take, and nearly always all that max_total kept boxes
+        // need; the later ones SORT_CAP
+        const uint32_t chunk_cap = cutoff == ~0ull ? (uint32_t)NMS_THREADS : (uint32_t)SORT_CAP;
         unsigned long long pivot = 0;
-        if (remaining > SORT_CAP) {
+        bool have_pivot = false;
+        if (cutoff == ~0ull && remaining > chunk_cap) {
+            // The first chunk need not hold EXACTLY chunk_cap keys: one histogram pass over 1024 score bins (score bits >> 14 from
+            // 0.25 up: any monotonic map of the key would do) and a suffix sum say from which bin up at most chunk_cap keys lie;
+            // that bin's lowest key is the pivot.  ~2 us where the exact radix select below takes eight passes, each with a
+            // serial scan of its 256 bins.  (A top bin that alone overflows the chunk -- a thousand equal scores -- falls through
+            // to the exact select.)
+            constexpr uint32_t BASE = 0x3e800000u >> 14;
+            uint32_t* const hb = (uint32_t*)sbox;                   // (the box slots are not in use yet)
+            const int lane = tid & 63, wv = tid >> 6;
+            hb[tid] = 0;
+            if (tid == 0) sh[3] = 0;                                // 1 + the pivot bin; stays 0 when not even the top bin fits
+            __syncthreads();
+            for (uint32_t i = tid; i < cnt; i += NMS_THREADS) {
+                const int x = (int)((uint32_t)(gk[i] >> 46)) - (int)BASE;
+                atomicAdd(&hb[x < 0 ? 0 : (x > 1023 ? 1023 : x)], 1u);
+            }
+            __syncthreads();
+            uint32_t suf = hb[tid];                                 // keys in bins tid .. 1023: the wave's suffix sum, then the later waves'
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_down(suf, o);
+                suf += lane + o < 64 ? v : 0u;
+            }
+            if (lane == 0) hb[1024 + wv] = suf;
+            __syncthreads();
+            for (int w = wv + 1; w < NMS_THREADS / 64; ++w) suf += hb[1024 + w];
+            // the lowest bin whose suffix fits the chunk (bin 0's suffix is `remaining`: it never does)
+            if (tid > 0 && suf <= chunk_cap && suf + hb[tid - 1] > chunk_cap) sh[3] = (uint32_t)tid + 1u;
+            __syncthreads();
+            const uint32_t pb = sh[3];
+            if (pb != 0) {
+                pivot = (unsigned long long)((pb - 1u + BASE) << 14) << 32;       // the bin's lowest key
+                have_pivot = true;
+            }
+            __syncthreads();
+        }
+        if (remaining > chunk_cap && !have_pivot) {
             unsigned long long prefix = 0, pmask = 0;
-            uint32_t need = SORT_CAP;
+            uint32_t need = chunk_cap;
             for (int shift = 56; shift >= 0; shift -= 8) {
                 for (int i = tid; i < 256; i += NMS_THREADS) hist[i] = 0;
                 __syncthreads();
@@ -402,7 +453,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
                 pmask |= 255ull << shift;
                 __syncthreads();
             }
-            pivot = prefix;                               // keys are unique: exactly SORT_CAP keys in [pivot, cutoff)
+            pivot = prefix;                               // keys are unique: exactly chunk_cap keys in [pivot, cutoff)
         }
         // ---- gather the chunk, sort it descending
         if (tid == 0) sh[0] = 0;
@@ -417,11 +468,11 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
                 if ((tid & 63) == 0) base = atomicAdd(&sh[0], (uint32_t)__popcll(mask));
                 base = __shfl(base, 0);
                 const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << (tid & 63)) - 1ull));
-                if (take && pos < SORT_CAP) skey[pos] = k;
+                if (take && pos < chunk_cap) skey[pos] = k;
             }
         }
         __syncthreads();
-        const uint32_t m = sh[0] < SORT_CAP ? sh[0] : SORT_CAP;
+        const uint32_t m = sh[0] < chunk_cap ? sh[0] : chunk_cap;
         uint32_t m2 = 64;
         while (m2 < m) m2 <<= 1;
         for (uint32_t i = m + tid; i < m2; i += NMS_THREADS) skey[i] = 0;
@@ -433,17 +484,35 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
             // network in LDS or in registers with shuffles, and as broadcasting the keys with v_readlane instead of LDS reads
             // (16 waves on one CU: LDS cycles of the broadcast reads here, instruction issue there) -- kept because it is the
             // shortest; the whole kernel went 80 -> 76.5 us with it and the wave-aggregated gather above.
+            // Round 4: the ranks come from a merge instead of all pairs -- every wave sorts its 64 keys in registers (21 shuffle
+            // stages), the sorted runs go back to LDS, and a key's rank is its place in its own run plus, per other run, the number
+            // of larger keys found by a 6-step binary search (the searches of the runs are independent chains): ~600 instructions
+            // per thread instead of ~3 500.
             unsigned long long* const xbuf = (unsigned long long*)sbox;
-            const unsigned long long key = (uint32_t)tid < m2 ? skey[tid] : 0ull;
-            uint32_t rank = 0;
-            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-#pragma unroll 4
-            for (uint32_t q = 0; q < m2; q += 2) {
-                const u64x2 kk = *(const u64x2*)(skey + q);
-                rank += (kk.x > key ? 1u : 0u) + (kk.y > key ? 1u : 0u);
+            unsigned long long key = (uint32_t)tid < m2 ? skey[tid] : 0ull;
+            const int lane = tid & 63, wv = tid >> 6;
+            for (int k = 2; k <= 64; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    const unsigned long long o = __shfl_xor(key, j);
+                    const bool want_max = ((lane & j) == 0) == ((lane & k) == 0);      // descending run
+                    key = (want_max ? o > key : o < key) ? o : key;
+                }
+            __syncthreads();
+            if ((uint32_t)tid < m2) skey[tid] = key;
+            __syncthreads();
+            uint32_t rank = (uint32_t)lane;
+            const int nruns = (int)(m2 >> 6);
+            for (int r = 0; r < nruns; ++r) {
+                if (r == wv) continue;                               // (wave-uniform)
+                const unsigned long long* run = skey + r * 64;
+                uint32_t lo = 0;                                     // number of keys of the run known to be larger
+#pragma unroll
+                for (int st = 32; st > 0; st >>= 1) lo += run[lo + st - 1] > key ? (uint32_t)st : 0u;
+                lo += run[lo] > key ? 1u : 0u;                       // (lo <= 63 here)
+                rank += lo;
             }
             __syncthreads();
-            if ((uint32_t)tid < m) xbuf[rank] = key;              // (the zero padding stays behind position m)
+            if ((uint32_t)tid < m2 && key != 0ull) xbuf[rank] = key;  // (keys are unique and non-zero; the zero padding stays behind position m)
             __syncthreads();
             if ((uint32_t)tid < m) skey[tid] = xbuf[tid];
             __syncthreads();
@@ -463,7 +532,80 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
         // lowest surviving lane is final, it is kept, its class and box are broadcast, and later same-class lanes test
         // against it.  Per candidate that is a few instructions instead of the ~90 of one-candidate-per-iteration on a wave
         // that retires one instruction per ~10 cycles (in-kernel timestamps: 41 us of this kernel were this pass).
-        if (tid < 64) {
+        // Round 4 -- the usual case (all of the image's candidates in one chunk of at most NMS_THREADS) runs ROUND-PARALLEL on every
+        // wave instead: one candidate per thread; in a round the lowest undecided candidate of every class (an LDS atomicMin per
+        // class) is final -- every earlier kept box of its class was such a head in an earlier round and it survived the test
+        // against it then -- so it is kept (class cap permitting) and the class's other undecided candidates test against it.
+        // The rounds stop once the candidates in front of the lowest undecided one hold max_total kept boxes; the kept boxes'
+        // ranks in sorted order are their output slots.  Same decisions as the sequential rule (same tests on the same pairs),
+        // in as many rounds as the busiest class among the leading candidates has kept boxes (bench input: ~7) of two
+        // barriers each, where the wave-0 pass below visits candidates 64 at a time at ~10 us per batch.
+        const bool par = p.C <= PAR_MAX_C && cutoff == ~0ull;      // (the first chunk: m <= NMS_THREADS; the kept lists it leaves are
+                                                                   // what the wave-0 pass of a later chunk continues from)
+        if (par) {
+            const uint32_t t = (uint32_t)tid;
+            const int lane = tid & 63;
+            const bool cap_binds = p.max_per_class < p.max_total;
+            bool und = t < m, keptf = false;
+            const unsigned long long key = und ? skey[t] : 0ull;
+            const float4 cb = und ? sbox[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t id = ~(uint32_t)(key & 0xffffffffull);
+            const uint32_t bi = fastdiv(id, p.div_c);
+            const int cls = und ? (int)(id - bi * (uint32_t)p.C) : 0;
+            for (int c = tid; c < p.C; c += NMS_THREADS) { pfirst[c] = PAR_NONE; pfirst[p.C + c] = PAR_NONE; pcount[c] = 0; }
+            if (tid == 0) { sh[8] = PAR_NONE; sh[9] = PAR_NONE; sh[10] = 0; sh[11] = 0; }
+            __syncthreads();
+            for (int r = 0;; ++r) {
+                const int b = r & 1;
+                uint32_t* const first = pfirst + b * p.C;
+                if (und) atomicMin(&first[cls], t);
+                {
+                    const unsigned long long mk = __ballot(und);
+                    if (mk && lane == __ffsll((long long)mk) - 1) atomicMin(&sh[8 + b], t);
+                }
+                __syncthreads();
+                const uint32_t U = sh[8 + b];                       // every candidate in front of U is decided
+                {
+                    const unsigned long long mk = __ballot(keptf && t < U);
+                    if (mk && lane == 0) atomicAdd(&sh[10 + b], (uint32_t)__popcll(mk));
+                }
+                const uint32_t h = und ? first[cls] : PAR_NONE;
+                const bool head = und && h == t;
+                if (head) {
+                    keptf = !cap_binds || (int)pcount[cls] < p.max_per_class;      // (the class's only head this round)
+                    if (keptf) pcount[cls] = pcount[cls] + 1;
+                    pflag[t] = keptf ? 1u : 0u;
+                    und = false;
+                }
+                if (tid == 0) { sh[8 + (b ^ 1)] = PAR_NONE; sh[10 + (b ^ 1)] = 0; }     // (last read before this round's first barrier)
+                __syncthreads();
+                if (U == PAR_NONE || sh[10 + b] >= (uint32_t)p.max_total) break;   // uniform
+                if (head) first[cls] = PAR_NONE;                    // (every thread read it before the barrier; next use: round r + 2)
+                if (und) {
+                    // a head that the class cap turned away suppresses nothing -- and everything later in its class is turned away too
+                    if (pflag[h] == 0u) und = false;
+                    else if (iou_tf(cb, sbox[h]) > p.iou_thr) und = false;
+                }
+            }
+            // output slot = number of kept candidates in front (sorted order)
+            const unsigned long long mk = __ballot(keptf);
+            uint32_t* const wtot = pflag + NMS_THREADS;
+            if (lane == 0) wtot[tid >> 6] = (uint32_t)__popcll(mk);
+            __syncthreads();
+            uint32_t slot = (uint32_t)__popcll(mk & ((1ull << lane) - 1ull)), total = 0;
+            for (int w = 0; w < NMS_THREADS / 64; ++w) {
+                const uint32_t c = wtot[w];
+                slot += w < (tid >> 6) ? c : 0u;
+                total += c;
+            }
+            if (keptf && slot < (uint32_t)p.max_total) {
+                kbox[slot] = cb;
+                kcls[slot] = cls;
+                kscore[slot] = __uint_as_float((uint32_t)(key >> 32));
+                kidx[slot] = (int)bi;
+            }
+            if (tid == 0) sh[1] = total < (uint32_t)p.max_total ? total : (uint32_t)p.max_total;
+        } else if (tid < 64) {
             int kept = (int)sh[1];
             const bool cap_binds = p.max_per_class < p.max_total;
             for (uint32_t t0 = 0; t0 < m && kept < p.max_total; t0 += 64) {
@@ -543,7 +685,10 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
     if (tid == 0) p.out_valid[n] = kept;
 }
 
-size_t nms_lds_bytes(int max_total) { return (size_t)SORT_CAP * 24 + (size_t)max_total * (16 + 12) + 256 * 4 + 64; }
+size_t nms_lds_bytes(int max_total, int classes) {
+    return (size_t)SORT_CAP * 24 + (size_t)max_total * (16 + 12) + 256 * 4 + 64 + (classes <= PAR_MAX_C ? (size_t)classes * 12 : 0) +
+           (size_t)(NMS_THREADS + 16) * 4;
+}
 
 int decode_launch(const DecodeK& k, hipStream_t stream, int clear_images) {
     // the per-image candidate counters are zero between steps (nms_kernel resets its image's); `clear_images` > 0: the caller
@@ -551,7 +696,11 @@ int decode_launch(const DecodeK& k, hipStream_t stream, int clear_images) {
     if (clear_images > 0) Y4_CHECK_HIP(hipMemsetAsync(k.counts, 0, sizeof(uint32_t) * (size_t)clear_images * COUNT_STRIDE, stream));
     if (3 * (5 + k.C) <= 256) {
         const int64_t cells = (int64_t)k.N * k.cells_per_img;
-        hipLaunchKernelGGL(decode_cell_kernel, dim3((int)((cells + 4 * DC_SCREEN - 1) / (4 * DC_SCREEN))), dim3(256), 0, stream, k);
+        // fewer than eight 16-cell waves per SIMD of the chip (up to 5 images at 608^2): 4-cell waves
+        if (cells < (int64_t)DC_SCREEN * 8192)
+            hipLaunchKernelGGL(decode_cell_kernel<DC_SCREEN_SMALL>, dim3((int)((cells + 4 * DC_SCREEN_SMALL - 1) / (4 * DC_SCREEN_SMALL))), dim3(256), 0, stream, k);
+        else
+            hipLaunchKernelGGL(decode_cell_kernel<DC_SCREEN>, dim3((int)((cells + 4 * DC_SCREEN - 1) / (4 * DC_SCREEN))), dim3(256), 0, stream, k);
     } else {
         const int64_t boxes = (int64_t)k.N * k.nbox;
         hipLaunchKernelGGL(decode_kernel, dim3((int)((boxes + 255) / 256)), dim3(256), 0, stream, k);
@@ -561,7 +710,7 @@ int decode_launch(const DecodeK& k, hipStream_t stream, int clear_images) {
 }
 
 int nms_launch(const NmsK& k, hipStream_t stream) {
-    const size_t lds = nms_lds_bytes(k.max_total);
+    const size_t lds = nms_lds_bytes(k.max_total, k.C);
     Y4_REQUIRE(lds <= 160 * 1024 && k.max_total <= 1024, Y4_EINVAL, "nms: max_total %d needs %zu bytes of LDS", k.max_total, lds);
     static PerDeviceOnce once;
     if (const uint64_t bit = once.due()) {
