@@ -59,7 +59,9 @@ struct TileCfg {
     X(45, 128, 128, 2, 2, 128, 4) \
     X(46, 64, 64, 2, 2, 128, 6)   \
     X(47, 128, 64, 4, 1, 128, 4)  \
-    X(48, 32, 64, 2, 2, 128, 7)
+    X(48, 32, 64, 2, 2, 128, 7)   \
+    X(49, 32, 64, 2, 2, 128, 5)   \
+    X(50, 64, 64, 2, 2, 128, 4)
 
 #define Y4_TILE_ROW(id, bm, bn, wm, wn, bkb, nst) {bm, bn, wm, wn, bkb, nst},
 static const TileCfg kTiles[] = {Y4_TILES(Y4_TILE_ROW)};
