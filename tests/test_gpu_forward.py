@@ -164,6 +164,26 @@ def test_batch_rows_independent_of_batch_size():
     eng.close()
 
 
+@pytest.mark.parametrize("dtype,size,ncls,n", [("bf16", 416, 80, 3), ("f32", 160, 3, 2), ("f16", 608, 80, 1)])
+def test_objectness_side_array_changes_nothing(dtype, size, ncls, n):
+    """Round 4: the head convs also leave their cells' objectness logits in a dense side array that decode's screen reads instead
+    of the cells (kernels.h: ConvObjDesc).  They are the stored logits themselves, so the detections of a forward pass (screen
+    from the side array) equal those of the same raw heads loaded back through y4_set_heads (which voids the array: screen from
+    the cells) bit for bit -- with the fusions on (two heads are LDS-pair tails at the 16-bit dtypes) and off."""
+    cfg, plan, ws, imgs, eng = _setup(size, ncls, n, dtype, seed=5)
+    for fused in (False, True):
+        if dtype != "f32":
+            eng.set_stem_fusion(fused); eng.set_chain_fusion(fused)
+        a = eng.predict(imgs, with_indices=True)
+        heads = [h.cpu().numpy() for h in eng.heads_device(n)]
+        eng.set_heads(heads)
+        b = [o.cpu().numpy() for o in eng.decode_nms_device(n)]
+        assert a[3].sum() > 0
+        for x, y in zip(a, b):
+            assert np.array_equal(np.asarray(x), y)
+    eng.close()
+
+
 def test_full_size_properties():
     """BASELINE.json's headline configuration (608x608, 80 classes, batch 32, bf16, fusions on) through size-independent
     properties: the step is deterministic (two runs bit-equal), every image of the batch equals that image run alone

@@ -39,6 +39,8 @@ struct ConvK {
     int fast_epi;
     unsigned fin_bytes, fin2_bytes;                    // the same for an LDS pair's tail (fast_tail)
     int fast_tail;
+    float* obj;                    // float32 head (out_f32): objectness side array (kernels.h: ConvObjDesc), or null
+    int obj_nf, obj_cpi, obj_base;
     FastDiv div_howo, div_wo;      // m -> (n, ho, wo) without integer division
     FastDiv div_gridn;
     char* out2;                    // channels >= split go to this view (fused CSP route + main-in pair)
@@ -249,6 +251,22 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[
             pix[0] = m;
         }
         if (p.out_f32) {
+            if (p.obj) {                                     // the cell's objectness logits, as stored, also to the side array
+                const int n = (int)fastdiv((uint32_t)m, p.div_howo), rem = m - n * HoWo;
+                float* const slot = p.obj + ((int64_t)n * p.obj_cpi + p.obj_base + rem) * 4;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const int e = a * p.obj_nf + 4 - ch[c];
+                        if (e >= 0 && e < 8) {
+                            float val = v[c * 8];
+#pragma unroll
+                            for (int q = 1; q < 8; ++q) val = e == q ? v[c * 8 + q] : val;
+                            slot[a] = val;
+                        }
+                    }
+            }
             for (int u = 0; u < npix; ++u) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c)

@@ -44,7 +44,7 @@ int conv_pick_tile(int dtype, int M, int cin, int cout) {
 }
 
 int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream, const ConvChainDesc* chain,
-                  const ConvPairDesc* pair) {
+                  const ConvPairDesc* pair, const ConvObjDesc* obj) {
     Y4_REQUIRE(d && d->in && d->wt && d->out && d->scale && d->shift, Y4_EINVAL, "conv2d: null pointer");
     Y4_REQUIRE(d->dtype >= Y4_F32 && d->dtype <= Y4_F16, Y4_EINVAL, "conv2d: bad dtype %d", d->dtype);
     Y4_REQUIRE(d->ksize == 1 || d->ksize == 3, Y4_EINVAL, "conv2d: ksize %d (only 1 or 3)", d->ksize);
@@ -88,6 +88,11 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
     k.res_cstride = d->res_cstride; k.res_coff = d->res_coff;
     k.ksize = d->ksize; k.stride = d->stride; k.pad = d->ksize == 3 ? 1 : 0;
     k.act = d->act; k.upsample = d->upsample; k.out_f32 = d->out_f32;
+    if (obj) {
+        Y4_REQUIRE(obj->obj && !d->upsample && ((pair && pair->out_f32) || (!pair && d->out_f32)), Y4_EINVAL,
+                   "conv2d: an objectness side array needs a float32 head");
+        k.obj = obj->obj; k.obj_nf = obj->nf; k.obj_cpi = obj->cells_per_img; k.obj_base = obj->cell_base;
+    }
     const int cout_pad = (int)round_up(d->cout, COUT_PAD);
     if (pair) {
         Y4_REQUIRE(!chain && d->dtype != Y4_F32 && (d->cout == 128 || d->cout == 256) && pair->cout >= 1 && pair->cout <= d->cout && !d->upsample &&

@@ -238,8 +238,13 @@ __global__ __launch_bounds__(256) void decode_cell_kernel(const DecodeK p) {
     const int c = lane >> 2, a = lane & 3;
     bool pass = false;
     if (a < 3 && c < DC_SCREEN && cell0 + c < ncell) {
-        const DecodeCell cl = decode_locate(p, cell0 + c);
-        pass = sigmoid_f(cl.src[a * nf + 4]) > p.score_thr;
+        // round 4: from the head convs' dense objectness array when they wrote one (one coalesced 16 bytes per cell: the same
+        // float32 logits), else from the cell itself
+        if (p.obj) pass = sigmoid_f(p.obj[(cell0 + c) * 4 + a]) > p.score_thr;
+        else {
+            const DecodeCell cl = decode_locate(p, cell0 + c);
+            pass = sigmoid_f(cl.src[a * nf + 4]) > p.score_thr;
+        }
     }
     unsigned long long m = __ballot(pass);
     if (!m) return;

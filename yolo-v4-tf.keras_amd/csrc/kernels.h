@@ -32,8 +32,15 @@ struct ConvPairDesc {
     void* fin2;                    // tail = a fused CSP pair (cout = both convs' rows): rows >= split go here
     int fin2_cstride, fin2_coff, split;
 };
+// A head conv (float32 raw logits) also leaves its three OBJECTNESS logits per cell -- channels a * nf + 4 -- in a dense side
+// array [image][cell of the image, the three scales back to back][4] (one 16-byte slot per cell), which is what decode's screen
+// reads instead of three 64-byte sectors of the 1 KB cell (decode_nms.hip).  The written values are the stored logits themselves.
+struct ConvObjDesc {
+    float* obj;                    // slot of this launch's first image's first cell
+    int nf, cells_per_img, cell_base;
+};
 int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stream, const ConvChainDesc* chain = nullptr,
-                  const ConvPairDesc* pair = nullptr);
+                  const ConvPairDesc* pair = nullptr, const ConvObjDesc* obj = nullptr);
 int pack_tail_weights(int dtype, int cout, int cin, const float* oihw, void* packed, hipStream_t stream);
 int conv_tile_count();
 bool weight_touch_enabled();          // conv_common.h: weight_touch (off with Y4_NO_WEIGHT_TOUCH=1, for A/B runs)
@@ -90,6 +97,7 @@ struct DecodeK {
     unsigned long long* keys;        // [N, cap]
     uint32_t* counts;                // [N * COUNT_STRIDE]: one counter per image, each on its own 256-byte line
     uint32_t cap;
+    const float* obj;                // [N * cells_per_img][4]: the cells' objectness logits as the head convs left them (ConvObjDesc), or null
 };
 struct NmsK {
     const float* dboxes;             // [N, nbox, 4]

@@ -98,7 +98,11 @@ struct y4_ctx {
     View heads[3];
     // workspace layout
     size_t act_bytes = 0, wts_bytes = 0;
-    size_t zero_off = 0, dbox_off = 0, keys_off = 0, counts_off = 0, status_off = 0, scratch_off = 0, splitk_off = 0;
+    size_t zero_off = 0, dbox_off = 0, keys_off = 0, counts_off = 0, status_off = 0, scratch_off = 0, splitk_off = 0, obj_off = 0;
+    // the cells' objectness logits beside the raw heads (kernels.h: ConvObjDesc): head i's are those of its images [0, obj_n[i])
+    // -- written by the head conv's own launch, so they ARE the stored logits; y4_set_heads writes heads only and voids them
+    int obj_n[3] = {-1, -1, -1};
+    int cells_per_img = 0, cell_base[3] = {0, 0, 0};
     // latency schedules: y4_autotune may pick split-K tile ids (conv_tiles.h); their counters + partial sums live at splitk_off
     bool allow_splitk = false;
     // decode's per-image candidate counters are zero (nms_kernel resets them); false: the next decode clears them itself
@@ -541,6 +545,9 @@ void layout(y4_ctx& c) {
     c.status_off = off; off = align256(off + 256);
     c.scratch_off = off; off = align256(off + nb * (size_t)c.cfg.max_total * 28 + nb * 4);
     c.splitk_off = off; off = align256(off + SPLITK_WS_BYTES);
+    c.cells_per_img = 0;
+    for (int i = 0; i < 3; ++i) { c.cell_base[i] = c.cells_per_img; c.cells_per_img += c.heads[i].side * c.heads[i].side; }
+    c.obj_off = off; off = align256(off + nb * (size_t)c.cells_per_img * 16);
     c.act_bytes = off;
     // ---- weights
     off = 0;
@@ -682,6 +689,20 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
     if (op.conv2 >= 0) { d.out2 = buf_ptr(h, op.out2, img0); d.out2_cstride = op.out2.cstride; d.out2_coff = op.out2.coff; d.split = op.split; }
     d.tile = chain ? chain->tile : op.tile;
     d.splitk_ws = h->act + h->splitk_off; d.splitk_ws_bytes = SPLITK_WS_BYTES;
+    // a float32 head (as a plain launch or as the tail of an LDS pair) also fills its cells' slots of the objectness array
+    ConvObjDesc od{};
+    const ConvObjDesc* odp = nullptr;
+    {
+        const Op* ho = op.out_f32 ? &op : (chain && chain->lds_pair && h->ops[chain->tail[0]].out_f32 ? &h->ops[chain->tail[0]] : nullptr);
+        if (ho)
+            for (int i = 0; i < 3; ++i)
+                if (h->heads[i].buf == ho->out.buf) {
+                    od.obj = (float*)(h->act + h->obj_off) + (size_t)img0 * h->cells_per_img * 4;
+                    od.nf = 5 + h->cfg.num_classes; od.cells_per_img = h->cells_per_img; od.cell_base = h->cell_base[i];
+                    odp = &od;
+                    h->obj_n[i] = img0 + n;
+                }
+    }
     if (chain && chain->lds_pair) {
         const Op& to = h->ops[chain->tail[0]];
         const Layer& TL = h->layers[to.conv];
@@ -695,7 +716,7 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
             pd.cout = 2 * TL.d.cout; pd.split = to.split;
             pd.fin2 = buf_ptr(h, to.out2, img0); pd.fin2_cstride = to.out2.cstride; pd.fin2_coff = to.out2.coff;
         }
-        return conv2d_launch(&d, h->act + h->zero_off, s, nullptr, &pd);
+        return conv2d_launch(&d, h->act + h->zero_off, s, nullptr, &pd, odp);
     }
     if (chain && chain->alt_of >= 0) {
         // this op (64 -> 64) feeds the conv over Concatenate([its output, route]) in registers; its own output is not stored
@@ -735,7 +756,7 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
         cd.fin = buf_ptr(h, last->out, img0); cd.fin_cstride = last->out.cstride; cd.fin_coff = last->out.coff;
         return conv2d_launch(&d, h->act + h->zero_off, s, &cd);
     }
-    return conv2d_launch(&d, h->act + h->zero_off, s);
+    return conv2d_launch(&d, h->act + h->zero_off, s, nullptr, nullptr, odp);
 }
 
 int run_decode_nms(y4_handle h, int n, float iou_thr, float score_thr, float* boxes, float* scores, float* classes,
@@ -758,6 +779,7 @@ int run_decode_nms(y4_handle h, int n, float iou_thr, float score_thr, float* bo
         k.keys = (unsigned long long*)(h->act + h->keys_off);
         k.counts = (uint32_t*)(h->act + h->counts_off);
         k.cap = h->cand_cap;
+        k.obj = h->obj_n[0] >= n && h->obj_n[1] >= n && h->obj_n[2] >= n ? (const float*)(h->act + h->obj_off) : nullptr;
         if (int r = decode_launch(k, s, h->counts_clean ? 0 : cfg.max_batch)) return r;
         h->counts_clean = false;                          // ... until this decode's NMS has been enqueued behind it
         h->counts_n = n;
@@ -997,6 +1019,7 @@ int y4_set_heads(y4_handle h, int n, const float* in_s, const float* in_m, const
     const float* ins[3] = {in_s, in_m, in_l};
     for (int i = 0; i < 3; ++i) {
         Y4_REQUIRE(ins[i], Y4_EINVAL, "y4_set_heads: null head %d", i);
+        h->obj_n[i] = -1;
         const View& v = h->heads[i];
         if (int r = f32_to_view_launch(ins[i], (float*)buf_ptr(h, v), (int64_t)n * v.side * v.side, v.cstride, v.c,
                                        (hipStream_t)stream))
