@@ -52,6 +52,14 @@ python bench.py --batch 1 --dtype f32 --no-cpu-baseline --no-latency --steps 50 
 scratch/ubench/mish_mfma > $O/ubench_mish_mfma.txt 2>&1
 [ -f scratch/libyolo4hip_cstr_all.so ] && YOLO4HIP_LIB=scratch/libyolo4hip_cstr_all.so python scripts/stage_trace.py > $O/stage_trace.txt 2>&1
 [ -f scratch/libyolo4hip_sdtr2.so ] && YOLO4HIP_LIB=scratch/libyolo4hip_sdtr2.so python scripts/stem_trace.py > $O/stem_trace.txt 2>&1
+[ -f scratch/libyolo4hip_rbtr128.so ] && YOLO4HIP_LIB=scratch/libyolo4hip_rbtr128.so python scripts/res_trace.py > $O/res_trace_128.txt 2>&1
+[ -f scratch/libyolo4hip_rbtr64.so ] && YOLO4HIP_LIB=scratch/libyolo4hip_rbtr64.so python scripts/res_trace.py > $O/res_trace_64.txt 2>&1
+# one image: the kernel timeline of a step on the shipped latency schedules (rocprofv3 --kernel-trace), bf16 and fp32
+for dt in bf16 f32; do
+  rocprofv3 --kernel-trace --output-format csv -d $O/b1_$dt -- python3 bench.py --batch 1 --dtype $dt --no-cpu-baseline --no-latency --in-flight 1 --steps 40 --warmup 5 --blocks 1 > $O/b1_$dt.json 2> $O/b1_$dt.err
+  python scripts/step_timeline.py $(ls $O/b1_$dt/*/*kernel_trace.csv | head -1) > $O/b1_${dt}_timeline.txt 2>&1
+  rm -rf $O/b1_$dt
+done
 for v in 0 1 0 1; do Y4_RB_PARTS=$v python bench.py --no-cpu-baseline --no-latency --in-flight 1 --load-tiles $O/tiles.json --steps 60 --blocks 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('Y4_RB_PARTS=$v one stream', d['value'], 'img/s, conv family', d['roofline']['kernel_ms_per_step'], 'ms, backbone', d['roofline']['backbone_wall']['one_stream'])"; done > $O/resblock_parts.txt 2>&1
 find $O -name "*.csv" -size +20M -delete
 find $O -name "*agent_info.csv" -delete
