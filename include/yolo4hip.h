@@ -270,7 +270,7 @@ int y4_pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* o
 int y4_conv2d(const y4_conv_desc* d, void* stream);
 int y4_conv_tile_count(void);
 /* Tile configuration `tile` (1 .. y4_conv_tile_count()): cfg = {BM pixels, BN channels, waves over pixels, waves over
- * channels, bytes of K per LDS row, schedule code (2..4 = ring stages, 12 = staggered 2-stage, 32 = 2-stage with the 32x32x16
+ * channels, bytes of K per LDS row, schedule code (2..7 = ring stages, 12 = staggered 2-stage, 32 = 2-stage with the 32x32x16
  * MFMA)}.  All tiles with the 16x16x32 MFMA give bit-identical results; the 32x32x16 tiles agree among themselves. */
 int y4_conv_tile_desc(int tile, int32_t cfg[6]);
 /* Latency schedules (the reference's own call is one image: Yolov4.predict, models.py:109-127).  With few images the deep layers

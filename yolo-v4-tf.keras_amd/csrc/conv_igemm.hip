@@ -154,7 +154,7 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
         const int S = 1 << split_e;
         const int64_t nwg = (int64_t)k.grid_m * k.grid_n, need = SPLITK_CNT_BYTES + nwg * S * tc.bm * tc.bn * 4;
         Y4_REQUIRE(!pair && !(chain && chain->ntail > 0) && splitk_tile(tile), Y4_EINVAL,
-                   "conv2d: tile id %d cannot run split-K (plain launches of the 2..4-stage ring tiles only)", d->tile);
+                   "conv2d: tile id %d cannot run split-K (plain launches of the 2..7-stage ring tiles only)", d->tile);
         Y4_REQUIRE(k.K / (tc.bkb / es) >= 2 * S, Y4_EINVAL, "conv2d: tile id %d: %d K-tiles are too few for a %d-way split", d->tile,
                    k.K / (tc.bkb / es), S);
         Y4_REQUIRE(d->splitk_ws && nwg <= SPLITK_CNT_BYTES / 4 && (int64_t)d->splitk_ws_bytes >= need, Y4_EINVAL,

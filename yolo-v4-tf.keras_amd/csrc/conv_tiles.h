@@ -82,7 +82,7 @@ inline bool tuner_skips_tile(int tile) { return mfma32_tile(tile) || (tile >= 1 
 // Split-K (small batches: fewer tiles than compute units and a long serial K loop): tile id = base + 100 e runs base tile `base`
 // with its K loop split 2^e ways over 2^e workgroups per output tile.  A split run adds its partial sums in split order: a fixed
 // fp32 summation order, but not the unsplit loop's -- like the 32x32x16 tiles these ids are never offered by the bit-identical
-// tuner, only by y4_autotune after y4_set_splitk(h, 1).  Base tiles: the plain ring schedules (2..4 stages).
+// tuner, only by y4_autotune after y4_set_splitk(h, 1).  Base tiles: the plain ring schedules (2..7 stages).
 constexpr int SPLITK_MAX_E = 3;
 constexpr int SPLITK_CNT_BYTES = 16 * 1024;          // 4096 tile counters in front of the partial sums
 constexpr size_t SPLITK_WS_BYTES = SPLITK_CNT_BYTES + (size_t)32 * 1024 * 1024;      // what an engine's workspace reserves for it
