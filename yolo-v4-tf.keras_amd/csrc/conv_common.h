@@ -309,9 +309,12 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[
 // the chunks' offsets immediates -- where the general path above pays 64-bit pointer arithmetic and a view select per store (its
 // ISA: ~200 VALU instructions per pixel row beside the ~80 of the activation), and the residual rows are loaded two rows ahead of
 // their use instead of in front of it.  Same values, same order of operations on them: bit-identical.
-template <int DT, int MREP, int NREP, int ACT, bool RES, int GW>
+// XL (an LDS pair's head): the packed tile goes to LDS in the K loop's pixel-operand layout instead (conv_epilogue_impl), nothing to
+// memory here -- the row's swizzle term is the lane's (rows 16 apart share their low bits), so a chunk's LDS address is a per-lane base
+// plus a compile-time row stride.
+template <int DT, int MREP, int NREP, int ACT, bool RES, int GW, bool XL = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvK& p, f32x4 (&acc)[MREP][NREP], const float* sc, const float* sh, int mrow,
-                                                   int chw, int fg) {
+                                                   int chw, int fg, char* xl = nullptr, int xrow = 0, int xpanel = 0) {
     using E = Elem<DT>;
     constexpr int EPC = E::EPC, ES = 16 / EPC, NC = NREP / 2, SPC = 8 / EPC;      // SPC: 16-byte stores per 8-channel chunk
     constexpr bool FAST = (DT != Y4_F32);
@@ -322,6 +325,15 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& p, f32x4 (&acc)[
     const int nfirst = p.split > 0 ? min(max((p.split - chw_u) / (GW * 8), 0), NC) : NC;
     const int lane1 = (p.out_coff + chw + fg * 8) * ES, lane2 = (p.out2_coff + chw - p.split + fg * 8) * ES;
     const int row1 = p.out_cstride * ES, row2 = p.out2_cstride * ES;
+    char* xbase[NC];
+    if constexpr (XL) {
+        static_assert(!XL || (EPC == 8 && GW == 4), "LDS pair: 16-bit dtypes, 16x16 tiles");
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = chunk_channel_g<GW>(chw, c, fg);
+            xbase[c] = xl + (ch >> 6) * xpanel + xrow * 128 + ((((ch & 63) >> 3) ^ (xrow & 7)) * 16);
+        }
+    }
     u32x4 res[RES ? 3 : 1][NC * SPC];
     const __amdgpu_buffer_rsrc_t rsr = make_rsrc(RES ? p.res : p.out, RES ? p.res_bytes : p.out_bytes);
     const int laner = (p.res_coff + chw + fg * 8) * ES, rowr = p.res_cstride * ES;
@@ -361,7 +373,8 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& p, f32x4 (&acc)[
             for (int h = 0; h < SPC; ++h) {
                 u32x4 pk;
                 E::store_chunk(&pk, v + c * 8 + h * EPC);
-                if (c < nfirst) buffer_store16(rs1, pk, o1 + c * CSTEP + h * 16);
+                if constexpr (XL) *(u32x4*)(xbase[c] + i * 16 * 128) = pk;
+                else if (c < nfirst) buffer_store16(rs1, pk, o1 + c * CSTEP + h * 16);
                 else buffer_store16(rs2, pk, o2 + c * CSTEP + h * 16);
             }
     }
@@ -389,10 +402,10 @@ __device__ __forceinline__ void conv_epilogue_with(const ConvK& p, f32x4 (&acc)[
                                                    int mrow, int m_limit, int chw, int fg, bool full, char* xl = nullptr, int xrow = 0,
                                                    int xpanel = 0) {
     // the activation and the mask mode are compile-time inside; one uniform switch outside the pixel loop
-    if (Y4_FAST_EPI && !XL && GW == 4 && full && p.fast_epi && p.act != Y4_ACT_LINEAR && (p.act == Y4_ACT_MISH || !p.res)) {
-        if (p.act == Y4_ACT_LEAKY) conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_LEAKY, false, GW>(p, acc, sc, sh, mrow, chw, fg);
-        else if (p.res) conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_MISH, true, GW>(p, acc, sc, sh, mrow, chw, fg);
-        else conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_MISH, false, GW>(p, acc, sc, sh, mrow, chw, fg);
+    if (Y4_FAST_EPI && GW == 4 && full && p.fast_epi && p.act != Y4_ACT_LINEAR && (p.act == Y4_ACT_MISH || !p.res)) {
+        if (p.act == Y4_ACT_LEAKY) conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_LEAKY, false, GW, XL>(p, acc, sc, sh, mrow, chw, fg, xl, xrow, xpanel);
+        else if (p.res) conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_MISH, true, GW, XL>(p, acc, sc, sh, mrow, chw, fg, xl, xrow, xpanel);
+        else conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_MISH, false, GW, XL>(p, acc, sc, sh, mrow, chw, fg, xl, xrow, xpanel);
         return;
     }
     if (p.act == Y4_ACT_MISH) {

@@ -114,7 +114,10 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
 #ifdef Y4_TRACE
-    const bool tr_life_on = blockIdx.x == TR_WG && BM == Y4_TRACE_BM && BN == 256 && NST == Y4_TRACE_NST && CHAIN == 0 && !PAIR;
+#ifndef Y4_TRACE_PAIR
+#define Y4_TRACE_PAIR 0            // 1: the life trace of the LDS-pair head of that tile instead (points 3 head K loop done, 7 tile in LDS, 2' -> [2] unchanged, 4 all stores issued)
+#endif
+    const bool tr_life_on = blockIdx.x == TR_WG && BM == Y4_TRACE_BM && BN == 256 && NST == Y4_TRACE_NST && CHAIN == 0 && PAIR == (Y4_TRACE_PAIR != 0);
     unsigned long long tr_life[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     TR_LIFE(0, "s_memtime");
@@ -464,6 +467,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         // the same K order as its own kernel would -- bit-identical, one launch and one HBM read less.
         static_assert(BKB == 128 && DT != Y4_F32 && SN == 2 && !PHASED && !B_PART, "LDS pair: plain 2-stage, 128-byte rows");
         constexpr int XPANEL = BM * 128, NK2 = BN / 64, XBYTES = NK2 * XPANEL, W2STAGE = BN * 128;
+        TR_LIFE(3, "s_memtime");
         __syncthreads();                                   // every wave is done with the stage buffers X overwrites
         char* const xl = smem;
         const int xrow = wm * WPX + frow, mrow = m0 + xrow, chw = wn * WCH;
@@ -486,6 +490,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         stage_w2(0, 0);                                    // its round trip hides under the head's epilogue
         conv_epilogue<DT, MREP, NREP, true>(p, acc, mrow, p.M, chw, fg, m0 + BM <= p.M, xl, xrow, XPANEL);
         __syncthreads();                                   // X complete (ds_write -> lgkmcnt(0) -> barrier)
+        TR_LIFE(7, "s_memtime");
         f32x4 acc2[MREP][NREP];
 #pragma unroll
         for (int i = 0; i < MREP; ++i)
@@ -521,6 +526,15 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         p2.fast_epi = p.fast_tail; p2.out_bytes = p.fin_bytes; p2.out2_bytes = p.fin2_bytes;
         conv_epilogue<DT, MREP, NREP>(p2, acc2, mrow, p.M, chw, fg, (m0 + BM <= p.M) && BN <= p2.cout_store);
         if (p.store_x) pair_store_tile<DT, MREP, NREP>(p, xl, xrow, XPANEL, mrow, p.M, chw, fg);
+        TR_LIFE(4, "s_memtime");
+        TR_LIFE(6, "s_memrealtime");
+#ifdef Y4_TRACE
+        if (tr_life_on) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0)
+                for (int q2 = 0; q2 < 8; ++q2) y4_trace_life[wave * 8 + q2] = tr_life[q2];
+        }
+#endif
     } else {
         TR_LIFE(3, "s_memtime");
         if constexpr (NST != 12 && NST != 32) {
