@@ -4,9 +4,10 @@
     YOLO4HIP_LIB=scratch/libyolo4hip_trp.so python scripts/pair_trace.py [last_conv]
 
 Runs the 608/80/bf16 batch-32 model on the shipped schedule up to conv `last_conv` (default 43: the pair 42 -> 43, a 3x3 256->256 + 1x1 at
-38^2) -- the last pair-head launch is the traced one -- and prints for workgroup 8, per wave, the shader-clock offsets of: kernel entry,
-staging set-up done, first K-tile in, head K loop done, head tile in LDS (its epilogue + barrier), everything stored (tail K loop, tail
-epilogue, the head tile's own store), with the wall time from s_memrealtime."""
+38^2) -- the last pair-head launch is the traced one -- and prints for workgroup 8, per wave, the shader-clock offsets (from the first
+wave's "head K loop done") of: first K-tile in (not reliable: s_memtime results of the kernel's first instructions are not waited for),
+head K loop done, head tile in LDS (its epilogue + barrier), tail K loop done, tail epilogue done (its stores issued), the head tile's
+own store issued; with the wall time from s_memrealtime."""
 import ctypes as C
 import os
 import sys
@@ -33,9 +34,9 @@ life = (C.c_ulonglong * 64)()
 lib.y4_trace_read_life_fused.restype = C.c_int
 assert lib.y4_trace_read_life_fused(life) == 0, "not a Y4_TRACE build"
 L = np.array(life[:], dtype=np.int64).reshape(8, 8)
-cols = [0, 1, 2, 3, 7, 4]
-names = ["entry", "set-up", "first tile in", "head K loop done", "tile in LDS", "all stored"]
-l0 = L[:, 0].min()
+cols = [2, 3, 7, 0, 1, 4]
+names = ["first tile in", "head K loop done", "tile in LDS", "tail K loop done", "tail epilogue done", "all stored"]
+l0 = L[:, 3].min()
 print("pair head ending at conv %d, workgroup 8 (shader cycles from the first wave's entry):" % last)
 for w in range(8):
     r = L[w, cols] - l0

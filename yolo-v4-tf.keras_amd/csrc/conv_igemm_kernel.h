@@ -517,6 +517,9 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 #pragma unroll
                     for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc2[i][j], wf[kk][j], xf[kk][i]);
         }
+#if defined(Y4_TRACE) && Y4_TRACE_PAIR
+        TR_LIFE(0, "s_memtime");                           // (pair trace: slots 0 / 1 are re-used for the tail's K loop / epilogue)
+#endif
         // tail epilogue through the ordinary path: a ConvK that describes the 1x1 conv's output side
         ConvK p2 = p;
         p2.scale = p.tail[0].scale; p2.shift = p.tail[0].shift; p2.act = p.tail_act; p2.res = nullptr;
@@ -525,6 +528,9 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         p2.split = p.tail_split; p2.out2 = p.fin2; p2.out2_cstride = p.fin2_cstride; p2.out2_coff = p.fin2_coff;
         p2.fast_epi = p.fast_tail; p2.out_bytes = p.fin_bytes; p2.out2_bytes = p.fin2_bytes;
         conv_epilogue<DT, MREP, NREP>(p2, acc2, mrow, p.M, chw, fg, (m0 + BM <= p.M) && BN <= p2.cout_store);
+#if defined(Y4_TRACE) && Y4_TRACE_PAIR
+        TR_LIFE(1, "s_memtime");
+#endif
         if (p.store_x) pair_store_tile<DT, MREP, NREP>(p, xl, xrow, XPANEL, mrow, p.M, chw, fg);
         TR_LIFE(4, "s_memtime");
         TR_LIFE(6, "s_memrealtime");
