@@ -124,6 +124,18 @@ __device__ __forceinline__ u32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, int 
 template <int AUX = 0> __device__ __forceinline__ void buffer_store16(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, int voffset) {
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, 0, AUX);
 }
+// 16 bytes per lane at AGENT scope (relaxed atomics, dword by dword: the compiler emits the sc1 accesses and its own waits) -- coherent
+// between the XCDs' L2s without a cache write-back / invalidate (the split-K partial sums, conv_igemm_kernel.h)
+__device__ __forceinline__ void store16_agent(f32x4* ptr, f32x4 v) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __hip_atomic_store((float*)ptr + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 load16_agent(const f32x4* ptr) {
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = __hip_atomic_load((const float*)ptr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
 // one dword per lane, same addressing: used to TOUCH a cache line (the data lands in an LDS scratch nobody reads)
 __device__ __forceinline__ void buffer_load4_lds(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, int soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 4, voffset, soffset, 0, 0);
