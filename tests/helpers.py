@@ -31,7 +31,7 @@ def torch_dtype(dtype):
 
 
 def run_conv_gpu(x, cw, k, stride, act, dtype, residual=None, upsample=False, out_f32=False, tile=0,
-                 in_pad=(0, 0), out_pad=(0, 0)):
+                 in_pad=(0, 0), out_pad=(0, 0), splitk_repeats=1):
     """Run y4_conv2d on NHWC float32 numpy `x` (already representable in `dtype`).
     in_pad/out_pad = (channels before, channels after) of extra garbage around the view, to exercise
     channel-slice reads/stores.  Returns float32 NHWC output (the slice only) and the full out buffer."""
@@ -76,13 +76,16 @@ def run_conv_gpu(x, cw, k, stride, act, dtype, residual=None, upsample=False, ou
     if tile >= 100:                      # split-K tile id: counters (zero before the first use) + partial sums
         ws = torch.zeros(16 * 1024 + 32 * 1024 * 1024, dtype=torch.uint8, device=dev)
         d.splitk_ws = ws.data_ptr(); d.splitk_ws_bytes = ws.numel()
+    if ws is not None: ws[16 * 1024:].fill_(0xFF)       # the partial sums' scratch starts as NaNs: a stale read shows
     ext.check(lib.y4_conv2d(C.byref(d), ext.stream_ptr()))
-    if ws is not None:                   # a second launch on the same scratch: the counters were left at zero
-        first = out.clone()
-        out.fill_(-5.0)
-        ext.check(lib.y4_conv2d(C.byref(d), ext.stream_ptr()))
-        torch.cuda.synchronize()
-        assert torch.equal(first, out), "a split-K launch is not repeatable on its own scratch"
+    if ws is not None:                   # more launches on the same scratch: the counters were left at zero, and the last arriver
+        first = out.clone()              # must read THIS launch's partial sums (the scratch is poisoned in between)
+        for _ in range(splitk_repeats):
+            out.fill_(-5.0)
+            ws[16 * 1024:].fill_(0xFF)
+            ext.check(lib.y4_conv2d(C.byref(d), ext.stream_ptr()))
+            torch.cuda.synchronize()
+            assert torch.equal(first, out), "a split-K launch is not repeatable on its own scratch"
         assert int(ws[:16 * 1024].view(torch.int32).abs().sum()) == 0, "split-K tile counters not back at zero"
     torch.cuda.synchronize()
     full = out.float().cpu().numpy()

@@ -104,6 +104,25 @@ def test_all_tiles_agree(dtype):
     assert ran >= 4 and (dtype == "f32" or ran32 >= 2)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_splitk_fixup_sees_this_launch_partial_sums(dtype):
+    """The split-K fix-up has no cache maintenance any more (round 4: agent-scope accesses + "my stores have completed" instead of
+    __threadfence, conv_igemm_kernel.h): 25 launches each of two-, four- and eight-way splits on a scratch that is filled with NaNs
+    before every launch -- a last arriver that read anything but this launch's partial sums would not reproduce the first result,
+    which is held to the oracle."""
+    from yolo4hip.weights import ConvWeights
+    atol, rtol = TOL[dtype]
+    rng = np.random.default_rng(77)
+    for (k, cin, cout, side, tile) in [(3, 512, 512, 19, 148), (3, 256, 512, 19, 210), (1, 1024, 512, 19, 349), (3, 512, 1024, 13, 308)]:
+        x = quantize(rng.standard_normal((1, side, side, cin)).astype(np.float32), dtype)
+        cw = make_conv_weights(rng, cout, cin, k)
+        cwq = ConvWeights(w=quantize(cw.w, dtype), bn=cw.bn)
+        want = _ref(x, cwq, k, 1, "leaky", None, False)
+        got, _ = run_conv_gpu(x, cwq, k, 1, "leaky", dtype, tile=tile, splitk_repeats=25)
+        d = np.abs(got - want)
+        assert np.all(d <= atol + rtol * np.abs(want)), f"tile {tile} {k}x{k} {cin}->{cout}: max err {d.max():.3e}"
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_mfma32_tiles_vs_oracle(dtype):
     """The 32x32x16-MFMA tiles (schedule code 32) against the same float64 reference and tolerance as every other tile: a 3x3
