@@ -199,26 +199,6 @@ __device__ __forceinline__ void decode_one_cell(const DecodeK& p, const DecodeCe
         }
         st.fill = base;
     }
-    // box coordinates of the anchors that can have candidates (custom_layers.py:251-256)
-    float t[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float t0 = value_at(i), t1 = value_at(nf + i), t2 = value_at(2 * nf + i);
-        t[i] = lane == 0 ? t0 : (lane == 1 ? t1 : t2);
-    }
-    if (lane < 3 && (lane == 0 ? so[0] : (lane == 1 ? so[1] : so[2])) > p.score_thr) {
-        const int row = rem / g, col = rem - row * g;
-        const float bx = ((sigmoid_f(t[0]) * p.xyscale[s]) - p.xyoff[s] + (float)col) * (float)p.stride[s];
-        const float by = ((sigmoid_f(t[1]) * p.xyscale[s]) - p.xyoff[s] + (float)row) * (float)p.stride[s];
-        const float bw = expf(t[2]) * p.anchors[(s * 3 + lane) * 2 + 0];
-        const float bh = expf(t[3]) * p.anchors[(s * 3 + lane) * 2 + 1];
-        float4 o;
-        o.x = (bx - bw / 2.0f) / p.img_size;
-        o.y = (by - bh / 2.0f) / p.img_size;
-        o.z = (bx + bw / 2.0f) / p.img_size;
-        o.w = (by + bh / 2.0f) / p.img_size;
-        *(float4*)(p.dboxes + ((int64_t)n * p.nbox + box0 + lane) * 4) = o;
-    }
 }
 
 // A wave first SCREENS 16 consecutive cells: lane (c, a) = (lane >> 2, lane & 3 < 3) reads the one objectness logit of
@@ -245,6 +225,26 @@ __global__ __launch_bounds__(256) void decode_cell_kernel(const DecodeK p) {
             const DecodeCell cl = decode_locate(p, cell0 + c);
             pass = sigmoid_f(cl.src[a * nf + 4]) > p.score_thr;
         }
+    }
+    // Round 4: the box of every (cell, anchor) that passed -- the condition under which decode_one_cell used to compute it on 3 of its
+    // 64 lanes, once per flagged cell -- is computed HERE, one per lane, for all of the wave's cells at once (custom_layers.py:251-256;
+    // the four box logits come from the cell: its lines are read by the full-cell load anyway)
+    if (pass) {
+        const DecodeCell cl = decode_locate(p, cell0 + c);
+        const int s = cl.s, g = p.g[s];
+        const float* tp = cl.src + a * nf;
+        const float t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+        const int row = cl.rem / g, col = cl.rem - row * g;
+        const float bx = ((sigmoid_f(t0) * p.xyscale[s]) - p.xyoff[s] + (float)col) * (float)p.stride[s];
+        const float by = ((sigmoid_f(t1) * p.xyscale[s]) - p.xyoff[s] + (float)row) * (float)p.stride[s];
+        const float bw = expf(t2) * p.anchors[(s * 3 + a) * 2 + 0];
+        const float bh = expf(t3) * p.anchors[(s * 3 + a) * 2 + 1];
+        float4 o;
+        o.x = (bx - bw / 2.0f) / p.img_size;
+        o.y = (by - bh / 2.0f) / p.img_size;
+        o.z = (bx + bw / 2.0f) / p.img_size;
+        o.w = (by + bh / 2.0f) / p.img_size;
+        *(float4*)(p.dboxes + ((int64_t)cl.n * p.nbox + p.box_off[s] + cl.rem * 3 + a) * 4) = o;
     }
     unsigned long long m = __ballot(pass);
     if (!m) return;
