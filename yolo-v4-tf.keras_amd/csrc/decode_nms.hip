@@ -142,23 +142,12 @@ __device__ __forceinline__ void decode_flush(const DecodeK& p, DecodeStage& st, 
     }
 }
 
-__device__ __forceinline__ void decode_one_cell(const DecodeK& p, const DecodeCell& cl, const float (&v)[4], int lane, DecodeStage& st) {
+__device__ __forceinline__ void decode_one_cell(const DecodeK& p, const DecodeCell& cl, const float (&v)[4], const float (&so)[3], int lane,
+                                                DecodeStage& st) {
     const int n = cl.n, s = cl.s, rem = cl.rem;
     const int g = p.g[s];
     const int nf = 5 + p.C, nval = 3 * nf;
-    auto value_at = [&](int e) {            // wave-uniform e: value e of the cell
-        const int k = e >> 6;
-        const float sel = k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3]));
-        return __shfl(sel, e & 63);
-    };
-    float so[3];
-    bool any = false;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        so[a] = sigmoid_f(value_at(a * nf + 4));
-        any = any || so[a] > p.score_thr;
-    }
-    if (!any) return;                       // wave-uniform
+    // so[a] = sigmoid(objectness of anchor a): the screen's value for this cell (the same float32 logit through the same sigmoid_f)
     const int box0 = p.box_off[s] + rem * 3;
     if (n != st.img || st.fill + 3 * p.C > DC_STAGE) { decode_flush(p, st, lane); st.img = n; }     // wave-uniform
     const float cut = 0.998f * p.score_thr;
@@ -217,14 +206,16 @@ __global__ __launch_bounds__(256) void decode_cell_kernel(const DecodeK p) {
     const int nf = 5 + p.C, nval = 3 * nf;
     const int c = lane >> 2, a = lane & 3;
     bool pass = false;
+    float sig = 0.f;                          // sigmoid(objectness) of this lane's (cell, anchor)
     if (a < 3 && c < DC_SCREEN && cell0 + c < ncell) {
         // round 4: from the head convs' dense objectness array when they wrote one (one coalesced 16 bytes per cell: the same
         // float32 logits), else from the cell itself
-        if (p.obj) pass = sigmoid_f(p.obj[(cell0 + c) * 4 + a]) > p.score_thr;
+        if (p.obj) sig = sigmoid_f(p.obj[(cell0 + c) * 4 + a]);
         else {
             const DecodeCell cl = decode_locate(p, cell0 + c);
-            pass = sigmoid_f(cl.src[a * nf + 4]) > p.score_thr;
+            sig = sigmoid_f(cl.src[a * nf + 4]);
         }
+        pass = sig > p.score_thr;
     }
     // Round 4: the box of every (cell, anchor) that passed -- the condition under which decode_one_cell used to compute it on 3 of its
     // 64 lanes, once per flagged cell -- is computed HERE, one per lane, for all of the wave's cells at once (custom_layers.py:251-256;
@@ -248,26 +239,30 @@ __global__ __launch_bounds__(256) void decode_cell_kernel(const DecodeK p) {
     }
     unsigned long long m = __ballot(pass);
     if (!m) return;
-    auto next_cell = [&](DecodeCell& cl, float (&v)[4]) {        // pops the lowest flagged cell and issues its loads
+    auto next_cell = [&](DecodeCell& cl, float (&v)[4], float (&so)[3]) {        // pops the lowest flagged cell and issues its loads
         const int cc = (__ffsll((long long)m) - 1) >> 2;
         m &= ~(0xFull << (4 * cc));
         cl = decode_locate(p, cell0 + cc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) so[k] = __shfl(sig, cc * 4 + k);
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = (lane + 64 * k < nval) ? cl.src[lane + 64 * k] : 0.f;
     };
     __shared__ unsigned long long stage[4][DC_STAGE];
     DecodeStage st{stage[wave], 0u, -1};
     DecodeCell cur, nxt;
-    float vc[4], vn[4];
-    next_cell(cur, vc);
+    float vc[4], vn[4], sc[3], sn[3];
+    next_cell(cur, vc, sc);
     while (true) {                                                // wave-uniform: the next flagged cell's loads fly under this one
         const bool more = m != 0;
-        if (more) next_cell(nxt, vn);
-        decode_one_cell(p, cur, vc, lane, st);
+        if (more) next_cell(nxt, vn, sn);
+        decode_one_cell(p, cur, vc, sc, lane, st);
         if (!more) break;
         cur = nxt;
 #pragma unroll
         for (int k = 0; k < 4; ++k) vc[k] = vn[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sc[k] = sn[k];
     }
     decode_flush(p, st, lane);
 }
