@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeK p) {
 struct DecodeCell { int n, s, rem; const float* src; };
 __device__ __forceinline__ DecodeCell decode_locate(const DecodeK& p, int64_t cellid) {
     DecodeCell c;
-    c.n = (int)(cellid / p.cells_per_img);
-    c.rem = (int)(cellid - (int64_t)c.n * p.cells_per_img);
+    c.n = (int)fastdiv((uint32_t)cellid, p.div_cells);
+    c.rem = (int)cellid - c.n * p.cells_per_img;
     c.s = 0;
     if (c.rem >= p.g[0] * p.g[0]) { c.rem -= p.g[0] * p.g[0]; c.s = 1; if (c.rem >= p.g[1] * p.g[1]) { c.rem -= p.g[1] * p.g[1]; c.s = 2; } }
     const int g = p.g[c.s];
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void decode_cell_kernel(const DecodeK p) {
         const int s = cl.s, g = p.g[s];
         const float* tp = cl.src + a * nf;
         const float t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
-        const int row = cl.rem / g, col = cl.rem - row * g;
+        const int row = (int)fastdiv((uint32_t)cl.rem, p.div_g[s]), col = cl.rem - row * g;
         const float bx = ((sigmoid_f(t0) * p.xyscale[s]) - p.xyoff[s] + (float)col) * (float)p.stride[s];
         const float by = ((sigmoid_f(t1) * p.xyscale[s]) - p.xyoff[s] + (float)row) * (float)p.stride[s];
         const float bw = expf(t2) * p.anchors[(s * 3 + a) * 2 + 0];
@@ -696,6 +696,7 @@ int decode_launch(const DecodeK& k, hipStream_t stream, int clear_images) {
     if (clear_images > 0) Y4_CHECK_HIP(hipMemsetAsync(k.counts, 0, sizeof(uint32_t) * (size_t)clear_images * COUNT_STRIDE, stream));
     if (3 * (5 + k.C) <= 256) {
         const int64_t cells = (int64_t)k.N * k.cells_per_img;
+        Y4_REQUIRE(cells < (1ll << 31), Y4_EINVAL, "decode: %lld cells exceed the 2^31 the cell -> image mapping divides exactly", (long long)cells);
         // fewer than eight 16-cell waves per SIMD of the chip (up to 5 images at 608^2): 4-cell waves
         if (cells < (int64_t)DC_SCREEN * 8192)
             hipLaunchKernelGGL(decode_cell_kernel<DC_SCREEN_SMALL>, dim3((int)((cells + 4 * DC_SCREEN_SMALL - 1) / (4 * DC_SCREEN_SMALL))), dim3(256), 0, stream, k);

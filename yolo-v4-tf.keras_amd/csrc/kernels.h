@@ -97,6 +97,7 @@ struct DecodeK {
     unsigned long long* keys;        // [N, cap]
     uint32_t* counts;                // [N * COUNT_STRIDE]: one counter per image, each on its own 256-byte line
     uint32_t cap;
+    FastDiv div_cells, div_g[3];     // cell id -> image, cell -> row (ids < 2^31: checked at y4_create)
     const float* obj;                // [N * cells_per_img][4]: the cells' objectness logits as the head convs left them (ConvObjDesc), or null
 };
 struct NmsK {

@@ -774,6 +774,8 @@ int run_decode_nms(y4_handle h, int n, float iou_thr, float score_thr, float* bo
         }
         memcpy(k.anchors, cfg.anchors, sizeof(k.anchors));
         k.cells_per_img = cells; k.N = n; k.C = cfg.num_classes; k.hcs = h->hcs; k.nbox = h->nbox;
+        k.div_cells = fastdiv_make((uint32_t)cells);
+        for (int i = 0; i < 3; ++i) k.div_g[i] = fastdiv_make((uint32_t)k.g[i]);
         k.img_size = (float)cfg.img_size; k.score_thr = score_thr;
         k.dboxes = (float*)(h->act + h->dbox_off);
         k.keys = (unsigned long long*)(h->act + h->keys_off);
