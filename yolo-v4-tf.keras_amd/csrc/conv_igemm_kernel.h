@@ -52,6 +52,10 @@ __device__ unsigned long long y4_trace_life[8 * 8];
 #define TR_LIFE(P, INSN)
 #endif
 
+#ifndef Y4_EARLY_ARGS
+#define Y4_EARLY_ARGS 1
+#endif
+
 template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0, bool PAIR = false>
 __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel(const ConvK p) {
     constexpr int NT = 64 * WM * WN;
@@ -89,6 +93,14 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
                   "32x32x16 tiles: 16-bit, 128-byte K rows, wave tile in 32x32 blocks, plain launches");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // The prologue's scalar fields in ONE round trip: hipcc fetches a kernel argument where it is first needed, and the shape fields
+    // (first used behind the tile-mapping branches) came one scalar-cache miss after the pointers -- a cold miss per workgroup that a
+    // short kernel feels (a single image: ~90 of them back to back).  Naming them here puts their loads into the first batch.
+#if Y4_EARLY_ARGS
+    asm volatile("" ::"s"(p.H), "s"(p.W), "s"(p.Cin), "s"(p.Ho), "s"(p.Wo), "s"(p.M), "s"(p.K), "s"(p.in_cstride), "s"(p.in_coff), "s"(p.ksize),
+                 "s"(p.stride), "s"(p.pad), "s"(p.grid_m), "s"(p.grid_n), "s"(p.in_bytes), "s"(p.wt_bytes), "s"(p.ksplit), "s"(p.touch));
+#endif
 
     // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous run of tiles with the
     //      channel tile fastest, so blocks sharing an activation row panel share an L2 (speed only).
