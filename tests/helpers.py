@@ -154,3 +154,49 @@ def shift_objectness(ws, num_classes, delta):
         b[4::5 + num_classes] += np.float32(delta)
         out[idx] = ConvWeights(w=cw.w, bn=cw.bn, bias=b)
     return out
+
+
+# ---------------------------------------------------------------- determinism helpers (tests/test_gpu_determinism.py)
+def tap_snapshot(eng, n):
+    """Every tensor the forward that just ran left behind, as DEVICE tensors in graph order: each materialised conv output
+    (y4_get_conv_output; convs inside a fused kernel are skipped), the three float32 heads, and the decode + NMS outputs."""
+    import torch
+    from yolo4hip import ext
+    if not hasattr(eng, "_lt"):
+        eng._lt = eng.layer_table()
+    snap = {}
+    if not getattr(eng, "alias_workspace", False):
+        for i, lt in enumerate(eng._lt):
+            side = lt["out_side"] * (2 if i in (78, 85) else 1)
+            out = torch.empty((n, side, side, lt["cout"]), dtype=torch.float32, device=eng.device)
+            if eng.lib.y4_get_conv_output(eng.handle, i, n, ext.ptr(out), out.numel(), ext.stream_ptr()) == 0:
+                snap[f"conv{i}"] = out
+    for k, h in enumerate(eng.heads_device(n)):
+        snap[f"head{k}"] = h
+    for name, t in zip(("boxes", "scores", "classes", "valid", "kept"), eng.decode_nms_device(n)):
+        snap[name] = t
+    torch.cuda.synchronize()
+    return snap
+
+
+def first_tap_difference(a, b, eng=None):
+    """None when the two snapshots are bit-identical, else a one-line description of the FIRST differing tensor in graph order
+    (the origin of a divergence): name, layer shape, how many elements differ, where, and by how much."""
+    import torch
+    for name in a:
+        if name not in b or torch.equal(a[name], b[name]):
+            continue
+        x, y = a[name].float(), b[name].float()
+        d = x != y
+        idx = d.nonzero()
+        where = idx[:4].cpu().numpy().tolist()
+        msg = f"{name}: {int(d.sum())} of {d.numel()} elements differ, first at {where}, max |delta| {float((x - y).abs().max()):.3e}"
+        if idx.shape[1] == 4:
+            ii = idx.cpu().numpy()
+            msg += (f", images {sorted(set(ii[:, 0].tolist()))}, rows {int(ii[:, 1].min())}..{int(ii[:, 1].max())}, cols "
+                    f"{int(ii[:, 2].min())}..{int(ii[:, 2].max())}, channels {int(ii[:, 3].min())}..{int(ii[:, 3].max())}")
+        if eng is not None and name.startswith("conv"):
+            lt = eng._lt[int(name[4:])]
+            msg += f" [k{lt['ksize']} s{lt['stride']} {lt['cin']}->{lt['cout']} @{lt['out_side']}]"
+        return msg
+    return None

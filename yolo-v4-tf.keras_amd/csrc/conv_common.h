@@ -146,14 +146,16 @@ __device__ __forceinline__ void buffer_load4_lds(__amdgpu_buffer_rsrc_t rsrc, ch
 // against 50 in a hot loop, its 1x1 neighbours 19 against 13).  So the workgroups that run together on an XCD (blockIdx.x >> 3
 // counts them; at most 32 CUs) share out the `bytes` of the block they are all about to stream and touch it once, one
 // dword per 128-byte line, before their first stage: about one load instruction per wave, every miss in flight together,
-// and the ring's loads then hit L2.  The dwords land in an LDS scratch of 256 bytes per wave that nobody reads -- callers
-// pass the wave's own first staging piece, which its own first stage load (issued later; a wave's loads retire in order)
-// overwrites.  No arithmetic is involved: results cannot change.
-__device__ __forceinline__ void weight_touch(__amdgpu_buffer_rsrc_t rs, char* wave_scratch, int byte0, int bytes, int wave, int nwaves, int lane) {
+// and the ring's loads then hit L2.  The dwords land in `scratch`: TOUCH_LDS bytes of LDS that belong to the touch alone
+// (round 5; every wave of the workgroup writes the same 256 bytes, nobody ever reads them).  Until round 4 the scratch was the
+// wave's own first staging piece, correct only as long as a wave's LDS-DMA loads LAND in issue order; nothing observable
+// rests on that ordering any more.  No arithmetic is involved: results cannot change.
+constexpr int TOUCH_LDS = 256;
+__device__ __forceinline__ void weight_touch(__amdgpu_buffer_rsrc_t rs, char* scratch, int byte0, int bytes, int wave, int nwaves, int lane) {
     const int me = ((int)blockIdx.x >> 3) & 31;
     const int lines = bytes >> 7;
     for (int i = (me * nwaves + wave) * 64 + lane; i < lines; i += 32 * nwaves * 64)
-        buffer_load4_lds(rs, wave_scratch, byte0 + i * 128, 0);
+        buffer_load4_lds(rs, scratch, byte0 + i * 128, 0);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);

@@ -79,11 +79,9 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     constexpr int STAGE = (BM + BN) * BKB;
     constexpr int KSTEPS = BKB / 64;        // MFMA k-steps (4 chunks each) per tile
     static_assert(BM % 16 == 0 && (BN % RPI == 0 || (RPI % BN == 0 && (BN * CPR) % 64 == 0)), "tile rows vs rows-per-iteration");
-    // weight_touch() parks its dwords in `smem + wave_lds`, i.e. in rows wave*8 .. +7 of stage 0's A region, and relies on THIS
-    // wave's own j = 0 activation load of stage(0) overwriting them later (a wave's loads retire in order).  That load exists for
-    // every wave only while no wave's first row lies past the tile (r0 < BM for all waves <=> RPI <= BM); with RPI > BM the
-    // scratch of the upper waves would sit in rows that ANOTHER wave's weight load fills -- a cross-wave LDS race.
-    static_assert(RPI <= BM, "weight_touch scratch must be a piece the same wave's first stage load overwrites");
+    // LDS: the K loop's stages (+ a chain's weight fragments) | TOUCH_LDS bytes that only weight_touch() writes.  An LDS pair's
+    // tail region (launch_cfg: lds_pair) overlays all of it after the K loop, when the touch has long landed.
+    constexpr int LDS_MAIN = SN * STAGE + (CHAIN ? ChainShape<CHAIN ? CHAIN : 1>::LDS_BYTES : 0);
     static_assert(MREP >= 1 && NREP >= 1, "wave tile");
     constexpr int LPT = A_IT + B_IT;        // LDS-DMA instructions a wave issues per stage
     static_assert(SN >= 2 && SN <= 7 && (SN == 2 || !B_PART), "deep pipelines need uniform weight loads per wave");
@@ -231,9 +229,9 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 
     // ---- weight touch (conv_common.h): this channel tile's weight block, BN rows x K, is contiguous
     if (p.touch != 0) {
-        weight_touch(rs_wt, smem + wave_lds, n0 * p.K * ES, BN * p.K * ES, wave, NT / 64, lane);
+        weight_touch(rs_wt, smem + LDS_MAIN, n0 * p.K * ES, BN * p.K * ES, wave, NT / 64, lane);
         if constexpr (PAIR)                    // ... and the tail conv's, needed only after the whole K loop
-            weight_touch(make_rsrc(p.tail[0].w, p.tail_w_bytes), smem + wave_lds, 0, (int)p.tail_w_bytes, wave, NT / 64, lane);
+            weight_touch(make_rsrc(p.tail[0].w, p.tail_w_bytes), smem + LDS_MAIN, 0, (int)p.tail_w_bytes, wave, NT / 64, lane);
     }
 
     // ---- fragment read addresses (row & swizzle depend on the lane only)
@@ -613,7 +611,8 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 // ------------------------------------------------------------------------------------------- launch
 template <int DT, int BM, int BN, int WM, int WN, int BKB, int NST, int CHAIN = 0, bool PAIR = false>
 static int launch_cfg(const ConvK& k, hipStream_t stream) {
-    constexpr int lds_main = (NST == 12 || NST == 32 ? 2 : NST) * (BM + BN) * BKB + (CHAIN ? ChainShape<CHAIN ? CHAIN : 1>::LDS_BYTES : 0);
+    // (the kernel's LDS_MAIN + the weight touch's own scratch)
+    constexpr int lds_main = (NST == 12 || NST == 32 ? 2 : NST) * (BM + BN) * BKB + (CHAIN ? ChainShape<CHAIN ? CHAIN : 1>::LDS_BYTES : 0) + TOUCH_LDS;
     constexpr int lds_pair = PAIR ? (BN / 64) * BM * 128 + 2 * BN * 128 : 0;     // tile panels + two weight stages of the tail
     constexpr int lds = lds_main > lds_pair ? lds_main : lds_pair;
     static_assert(lds <= 160 * 1024, "LDS budget");

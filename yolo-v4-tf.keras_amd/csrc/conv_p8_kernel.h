@@ -171,9 +171,8 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(p.wt, p.wt_bytes);
     const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
-    // (the touch scratch smem + wave_lds is region 0 / stage 0's piece of THIS wave: issue_a(0, 0) below, which every one of the
-    //  eight waves issues -- all waves stage every region -- overwrites it in order)
-    if (p.touch != 0) weight_touch(rs_wt, smem + wave_lds, n0 * p.K * ES, 256 * p.K * ES, wave, 8, lane);     // conv_common.h
+    // (the touch has its own TOUCH_LDS bytes behind the two K-tiles: conv_common.h)
+    if (p.touch != 0) weight_touch(rs_wt, smem + 2 * STAGE, n0 * p.K * ES, 256 * p.K * ES, wave, 8, lane);
     const int nk = p.K / BK;
     // staging cursor: the K-tile whose regions are being issued (tap, byte offset of c0, byte offset of k in the weights)
     int tap = 0, ky = 0, kx = 0, c0b = 0, ktb = 0, lk = 0;
@@ -379,7 +378,7 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
 
 template <int DT, int BM, int SCHED>
 static int launch_p8_cfg(const ConvK& k, hipStream_t stream) {
-    constexpr int lds = 2 * (BM + 256) * 128;
+    constexpr int lds = 2 * (BM + 256) * 128 + TOUCH_LDS;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv_p8_kernel<DT, BM, SCHED>;
     static PerDeviceOnce once;

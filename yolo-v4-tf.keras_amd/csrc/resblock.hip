@@ -92,7 +92,11 @@ template <int C, int TY = RB_T> struct RbGeom {
     static constexpr int AFF_PAD = (AFF_BYTES + 1023) / 1024 * 1024;
     static constexpr int BLOB_BYTES = AFF_PAD + NSTEPS * STEP_BYTES;      // [affine | W1 | W3]
     static constexpr int L_AFF = 0, L_RING = AFF_PAD, L_XT = L_RING + RING * STEP_BYTES;
-    static constexpr int LDS = L_XT + XT_PIECES * 1024;
+    // the weight touch's own TOUCH_LDS bytes (conv_common.h): the slack behind the tile's last pixel row inside its last 1 KB piece
+    // -- written by that piece's surplus lanes and by the touch, read by nobody -- or, where the slack is smaller, one more KB
+    static constexpr int XT_SLACK = XT_PIECES * 1024 - HROWS * (CPR + 1) * 16;
+    static constexpr int LDS = L_XT + XT_PIECES * 1024 + (XT_SLACK >= TOUCH_LDS ? 0 : 1024);
+    static constexpr int L_TOUCH = LDS - TOUCH_LDS;
     static constexpr int WN = NF / 4, WM = RB_WAVES / WN, MREP = TY / WM;         // wave grid of the 3x3 phase; NREP = 4
     static_assert(C != 64 || 2 * LDS <= 160 * 1024, "C = 64: two workgroups per compute unit (resblock_dispatch)");
     static_assert(LDS <= 160 * 1024 && MREP >= 1 && MREP * WM == TY && PPW >= 1 && PPW * RB_WAVES * 1024 == STEP_BYTES && NFA <= 3 * RB_WAVES,
@@ -142,9 +146,8 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.blob, G::BLOB_BYTES);
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes), rs_out = make_rsrc(p.out, p.out_bytes);
     // the blob (affine tables + both convs' weight streams: every tile streams all of it) -> this XCD's L2, shared out over the
-    // workgroups (conv_common.h: weight_touch); the dwords land in the wave's piece of ring slot 0, which its stage_w(0) overwrites
-    static_assert(G::PPW >= 1, "every wave must own piece `wave` of ring slot 0 (stage_w(0), k = 0): it is the touch scratch");
-    if (p.touch != 0) weight_touch(rb, ring + __builtin_amdgcn_readfirstlane(wave * 1024), 0, G::BLOB_BYTES, wave, RB_WAVES, lane);
+    // workgroups (conv_common.h: weight_touch); the dwords land in LDS bytes of their own (RbGeom::L_TOUCH)
+    if (p.touch != 0) weight_touch(rb, smem + G::L_TOUCH, 0, G::BLOB_BYTES, wave, RB_WAVES, lane);
     // affine -> LDS once per workgroup
     for (int u = wave; u < G::AFF_PAD / 1024; u += RB_WAVES)
         buffer_load16_lds(rb, smem + __builtin_amdgcn_readfirstlane(u * 1024), u * 1024 + lane * 16, 0);
