@@ -93,7 +93,8 @@ int y4_bind_workspace(y4_handle h, void* act_dev, size_t act_bytes, void* wts_de
  * float32 stream of a Darknet .weights file after its 20-byte header, already on the device: for conv
  * 0..109, [beta,gamma,mean,var] x cout (or cout biases for convs 93/101/109), then cout*cin*k*k weights in
  * (out,in,h,w) order.  Computes scale = gamma*rsqrt(var+1e-3), shift = beta-mean*scale (Keras BN eps) and
- * re-lays every kernel as [cout_pad][kh][kw][cin] in the handle's dtype inside the bound `wts` workspace. */
+ * re-lays every kernel along the library's canonical K order -- [cout_pad][cin/KC][kh*kw][KC], KC = min(cin, 64) for 3x3 and cin for 1x1
+ * kernels: 64-channel chunk, then tap, then channel -- in the handle's dtype inside the bound `wts` workspace. */
 int y4_pack_weights(y4_handle h, const float* darknet_floats_dev, size_t n_floats, void* stream);
 /* Multi-GPU: after rank 0 packed and the caller broadcast the whole `wts` workspace (RCCL), the other
  * ranks mark their copy as valid. */
@@ -262,7 +263,8 @@ typedef struct y4_conv_desc {
 
 /* cout_pad (rows of the packed matrix) and bytes needed for a packed kernel */
 int y4_packed_conv_bytes(int dtype, int cout, int cin, int ksize, int32_t* cout_pad, size_t* bytes);
-/* Darknet (cout,cin,k,k) float32 on device -> packed [cout_pad][k][k][cin] dtype; rows >= cout are zero */
+/* Darknet (cout,cin,k,k) float32 on device -> packed [cout_pad][cin/KC][k*k][KC] dtype (KC = min(cin, 64) for k = 3, cin for k = 1: the
+ * K order every conv kernel sums in); rows >= cout are zero */
 int y4_pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw_dev, void* packed_dev,
                          void* stream);
 /* One conv() unit of the reference (custom_layers.py:5-31) + optional Add (custom_layers.py:44) +

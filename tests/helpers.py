@@ -141,6 +141,15 @@ def detection_agreement(kept, classes, scores, boxes, valid, ri, rc, rs, rb, rv)
     return (len(common) / max(len(ref), 1)), ds, db
 
 
+def score_delta_quantile(kept, classes, scores, valid, ri, rc, rs, rv, q=0.9):
+    """The q-quantile of |score delta| over the detections two NMS results share (matched by box index and class): the bulk of
+    the distribution, where `detection_agreement`'s maximum is its tail."""
+    got = {(int(kept[j]), int(classes[j])): j for j in range(int(valid))}
+    ref = {(int(ri[j]), int(rc[j])): j for j in range(int(rv))}
+    d = [abs(float(scores[got[k]]) - float(rs[ref[k]])) for k in set(got) & set(ref)]
+    return float(np.quantile(d, q)) if d else 0.0
+
+
 def shift_objectness(ws, num_classes, delta):
     """A copy of a weight set whose three head convs (93, 101, 109: bias, no BN; custom_layers.py:141-198) have `delta` added to
     the bias of their objectness channels (channel 4 of each anchor's 5 + C block): with delta < 0 fewer boxes pass the score

@@ -120,9 +120,11 @@ def test_fp32_forward_and_nms_parity(size, ncls, n):
     eng.close()
 
 
-@pytest.mark.parametrize("dtype,tol,min_common", [("bf16", 0.45, 0.8), ("f16", 0.06, 0.93)])
+# (bounds = measured + ~15 %, VERDICT r4 item 4: bf16 99.9 % quantile 0.27-0.33 and 93-94 % matched at 416 / 3 classes / batch 2,
+#  fp16 0.034-0.040 and 98-99 %; the bulk / tail split of the score deltas is in tests/test_gpu_parity_full.py)
+@pytest.mark.parametrize("dtype,tol,min_common", [("bf16", 0.40, 0.86), ("f16", 0.049, 0.96)])
 def test_16bit_forward_close_to_fp32_oracle(dtype, tol, min_common):
-    """16-bit storage: heads stay close to the fp32 oracle.  Bounds = measured on MI355X + ~40 % (bf16: 99.9 % quantile of
+    """16-bit storage: heads stay close to the fp32 oracle.  Bounds = measured on MI355X + ~15 % (bf16: 99.9 % quantile of
     |logit error| 0.27-0.33, mean 0.05-0.06, 92-96 % of detections matched by (box, class); fp16: 0.034-0.042, 0.0064-0.0075,
     98-99 %); the budget of 110 layers of 8-/11-bit mantissa rounding on logits of std ~1.3."""
     from oracle import forward as OF, decode_nms as OD

@@ -48,6 +48,15 @@ inline int elem_size(int dtype) { return dtype == Y4_F32 ? 4 : 2; }
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 constexpr int COUT_PAD = 128;      // packed weight matrices have a multiple of this many rows
+// THE K order of every conv kernel (round 5).  The K axis of a k x k conv over Cin channels runs  chunk of KC channels (outer) ->
+// tap (ky, kx) -> channel inside the chunk,  KC = min(Cin, K_CHUNK) for 3x3 convs and Cin for 1x1 convs:
+//     k = (chunk * k*k + tap) * KC + c,    input channel = chunk * KC + c.
+// Packed weights are laid out along it ([cout_pad][Cin/KC][k*k][KC]), every kernel walks it in ascending order, and the MFMAs
+// accumulate in that order -- so all kernels of one dtype still agree bit for bit.  Until round 4 the order was tap-major
+// ([kh][kw][Cin]); chunk-major is what lets a kernel keep ONE 64-channel halo tile in LDS and run all nine taps from it
+// (conv_halo_kernel.h) without changing the sums.  For Cin <= 64 the two orders are the same.
+constexpr int K_CHUNK = 64;
+inline __host__ __device__ int k_chunk_channels(int cin, int ksize) { return ksize == 1 || cin < K_CHUNK ? cin : K_CHUNK; }
 constexpr int ZERO_PAGE_BYTES = 256;
 
 // ---- device-side storage conversions (bf16 is stored as raw uint16_t, fp16 as _Float16).

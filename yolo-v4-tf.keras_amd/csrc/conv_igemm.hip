@@ -179,14 +179,19 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
 }
 
 // ------------------------------------------------------------------------------ weight re-layout
+// Darknet (cout, cin, k, k) float32 -> [cout_pad][cin / KC][k*k][KC] in the storage type: the canonical K order of common.h
 template <int DT>
 __global__ void pack_conv_kernel(const float* __restrict__ w, typename Elem<DT>::type* __restrict__ out, int cout,
-                                 int cout_pad, int cin, int kk) {
+                                 int cout_pad, int cin, int kk, int kc) {
     const int64_t total = (int64_t)cout_pad * kk * cin;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % cin);
-        const int64_t r = i / cin;
-        const int tap = (int)(r % kk), co = (int)(r / kk);
+        const int c = (int)(i % kc);
+        int64_t r = i / kc;
+        const int tap = (int)(r % kk);
+        r /= kk;
+        const int nchunk = cin / kc;
+        const int chunk = (int)(r % nchunk), co = (int)(r / nchunk);
+        const int ci = chunk * kc + c;
         const float v = co < cout ? w[((int64_t)co * cin + ci) * kk + tap] : 0.f;
         out[i] = Elem<DT>::st(v);
     }
@@ -194,12 +199,14 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, typename Elem<DT>:
 
 int pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw, void* packed, hipStream_t stream) {
     const int cout_pad = (int)round_up(cout, COUT_PAD), kk = ksize * ksize;
+    const int kc = k_chunk_channels(cin, ksize);
+    Y4_REQUIRE(cin % kc == 0, Y4_EINVAL, "pack_conv_weights: cin %d is not a multiple of the K chunk %d", cin, kc);
     const int64_t total = (int64_t)cout_pad * kk * cin;
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     switch (dtype) {
-        case Y4_F32: hipLaunchKernelGGL(pack_conv_kernel<Y4_F32>, dim3(blocks), dim3(256), 0, stream, oihw, (float*)packed, cout, cout_pad, cin, kk); break;
-        case Y4_BF16: hipLaunchKernelGGL(pack_conv_kernel<Y4_BF16>, dim3(blocks), dim3(256), 0, stream, oihw, (uint16_t*)packed, cout, cout_pad, cin, kk); break;
-        case Y4_F16: hipLaunchKernelGGL(pack_conv_kernel<Y4_F16>, dim3(blocks), dim3(256), 0, stream, oihw, (_Float16*)packed, cout, cout_pad, cin, kk); break;
+        case Y4_F32: hipLaunchKernelGGL(pack_conv_kernel<Y4_F32>, dim3(blocks), dim3(256), 0, stream, oihw, (float*)packed, cout, cout_pad, cin, kk, kc); break;
+        case Y4_BF16: hipLaunchKernelGGL(pack_conv_kernel<Y4_BF16>, dim3(blocks), dim3(256), 0, stream, oihw, (uint16_t*)packed, cout, cout_pad, cin, kk, kc); break;
+        case Y4_F16: hipLaunchKernelGGL(pack_conv_kernel<Y4_F16>, dim3(blocks), dim3(256), 0, stream, oihw, (_Float16*)packed, cout, cout_pad, cin, kk, kc); break;
         default: set_error("pack_conv_weights: bad dtype %d", dtype); return Y4_EINVAL;
     }
     Y4_CHECK_HIP(hipGetLastError());

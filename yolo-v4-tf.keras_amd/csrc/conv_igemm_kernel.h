@@ -3,11 +3,12 @@
 // folded into its epilogue: residual Add (custom_layers.py:44), Concatenate (:68,:149,... -> a channel
 // slice store), UpSampling2D (:147,:159 -> 2x2 replicated store).
 //
-// GEMM view (NHWC activations):  D[ch][px] = sum_k Wt[ch][k] * X[px][k],  k = (ky*kw + kx)*Cin + ci
-//   X rows are gathered on the fly: for K-tile (tap, c0) row px is the BK contiguous channels
-//   in[n, ho*s+ky-pad, wo*s+kx-pad, c0:c0+BK]  (zero page when the tap falls in the padding),
-//   copied HBM/L2 -> LDS with global_load_lds (16 B per lane, no VGPR round trip).
-//   Weights are pre-packed [cout_pad][kh][kw][cin] so their K-tile rows are contiguous too.
+// GEMM view (NHWC activations):  D[ch][px] = sum_k Wt[ch][k] * X[px][k],  k in the canonical order of common.h:
+//   64-channel chunk -> tap -> channel (for Cin <= 64 and for 1x1 convs: tap -> channel).
+//   X rows are gathered on the fly: for K-tile (chunk, tap, c0) row px is the BK contiguous channels
+//   in[n, ho*s+ky-pad, wo*s+kx-pad, c0:c0+BK]  (an out-of-range offset -> zeros when the tap falls in the padding),
+//   copied HBM/L2 -> LDS with buffer_load ... lds (16 B per lane, no VGPR round trip).
+//   Weights are pre-packed along the same order ([cout_pad][Cin/KC][kh*kw][KC]) so their K-tile rows are contiguous too.
 // The weight fragment is the MFMA *A* operand and the pixel fragment the *B* operand, so the accumulator
 // layout is D[row = channel][col = pixel]: every lane ends up holding runs of 8 CONSECUTIVE channels of one
 // pixel (the channel <-> MFMA-row assignment is free; the "chunked" assignment of conv_common.h is applied as a
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
     // chunk swizzle of an LDS row: by the row's low bits (conv_common.h: swz); the 32x32x16 tiles also flip bit 0 with row
     // bit 4 -- their fragment reads put rows r and r + 16 (not r and r + 8 with the next chunk) into one ds_read_b128 lane group
     auto tswz = [](int row) { return M32 ? (swz<CPR>(row) ^ ((row >> 4) & 1)) : swz<CPR>(row); };
-    int a_off[A_IT], a_hi[A_IT], a_wi[A_IT];
+    int a_off[A_IT], a_mask[A_IT];         // a_mask: bit ky*ksize + kx = that tap of the row reads inside the image (else zeros)
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int j = 0; j < A_IT; ++j) {
@@ -158,8 +159,11 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         const int ho = (int)fastdiv((uint32_t)rem, p.div_wo), wo = rem - ho * p.Wo;
         const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
         a_off[j] = (((n * p.H + hi0) * p.W + wi0) * p.in_cstride + p.in_coff + ((q ^ tswz(row)) * EPC)) * ES;
-        a_hi[j] = m < p.M ? hi0 : -100000;     // rows past M never validate -> zeros
-        a_wi[j] = wi0;
+        int mask = 0;
+        for (int ky = 0; ky < p.ksize; ++ky)
+            for (int kx = 0; kx < p.ksize; ++kx)
+                if ((unsigned)(hi0 + ky) < (unsigned)p.H && (unsigned)(wi0 + kx) < (unsigned)p.W) mask |= 1 << (ky * p.ksize + kx);
+        a_mask[j] = m < p.M ? mask : 0;        // rows past M never validate -> zeros
     }
     int b_off[B_IT];
 #pragma unroll
@@ -185,26 +189,30 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
 
     // wave-uniform: does this wave skip the (partial) last A iteration?  (rows r0 + (A_IT-1)*RPI >= BM)
     const bool a_skip = A_PART && __builtin_amdgcn_readfirstlane(r0 + (A_IT - 1) * RPI >= BM ? 1 : 0) != 0;
-    int ky = 0, kx = 0, c0b = 0, ktb = 0;          // staging cursor: tap, byte offset of c0, byte offset of k in the weights
+    // staging cursor over the canonical K order (common.h): chunk of `chb` bytes of channels -> tap -> K-tile inside the chunk
+    const int chb = k_chunk_channels(p.Cin, p.ksize) * ES;
+    int ky = 0, kx = 0, cbase = 0, c_in = 0, ktb = 0;      // tap, byte offset of the chunk, of the K-tile in it, of k in the weights
     int nk = p.K / BK;                             // K-tiles this block walks
     if constexpr (CHAIN == 0 && !PAIR && NST != 12 && NST != 32) {
         if (p.ksplit > 1) {                        // this split's K range: cursor to its first K-tile
             const int kt0 = (int)((int64_t)ks * nk / p.ksplit), kt1 = (int)((int64_t)(ks + 1) * nk / p.ksplit);
-            const int e0 = kt0 * BK, tap = e0 / p.Cin;
+            const int per = chb / BKB;             // K-tiles per (chunk, tap)
+            const int idx = kt0 / per, taps = p.ksize * p.ksize;
+            const int chunk = idx / taps, tap = idx - chunk * taps;
             ky = tap / p.ksize; kx = tap - ky * p.ksize;
-            c0b = (e0 - tap * p.Cin) * ES;
+            cbase = chunk * chb;
+            c_in = (kt0 - idx * per) * BKB;
             ktb = kt0 * BKB;
             nk = kt1 - kt0;
         }
     }
+    int c0b = cbase + c_in;
     int a_vo[A_IT];
     auto set_tap = [&]() {
+        const int tap = ky * p.ksize + kx;
         const int tap_off = ((ky * p.W + kx) * p.in_cstride) * ES;
 #pragma unroll
-        for (int j = 0; j < A_IT; ++j) {
-            const bool ok = (unsigned)(a_hi[j] + ky) < (unsigned)p.H && (unsigned)(a_wi[j] + kx) < (unsigned)p.W;
-            a_vo[j] = ok ? a_off[j] + tap_off : (int)0x80000000;            // >= num_records -> reads as zero
-        }
+        for (int j = 0; j < A_IT; ++j) a_vo[j] = ((a_mask[j] >> tap) & 1) ? a_off[j] + tap_off : (int)0x80000000;   // >= num_records -> zeros
     };
     set_tap();
     auto stage = [&](int buf) {
@@ -219,12 +227,16 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
             if (!B_PART || tid < BN * CPR)                                   // wave-uniform predicate
                 buffer_load16_lds(rs_wt, smem + db + j * (NT * 16), b_off[j], ktb);
         ktb += BKB;
-        c0b += BKB;
-        if (c0b >= p.Cin * ES) {
-            c0b = 0;
-            if (++kx >= p.ksize) { kx = 0; ++ky; }
+        c_in += BKB;
+        if (c_in >= chb) {                          // next tap of this chunk; after the last tap the next chunk
+            c_in = 0;
+            if (++kx >= p.ksize) {
+                kx = 0;
+                if (++ky >= p.ksize) { ky = 0; cbase += chb; }
+            }
             set_tap();
         }
+        c0b = cbase + c_in;
     };
 
     // ---- weight touch (conv_common.h): this channel tile's weight block, BN rows x K, is contiguous

@@ -113,7 +113,9 @@ __global__ __launch_bounds__(768, 1) void conv_l12_kernel(const ConvK p) {
         }
         const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
         const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(p.wt, p.wt_bytes);
-        int tap = 0, ky = 0, kx = 0, c0b = 0, lk = 0;              // pixel cursor: the K-tile whose parts are being issued
+        // pixel cursor: the K-tile whose parts are being issued (canonical K order, common.h: chunk -> tap -> channel)
+        const int chb = k_chunk_channels(p.Cin, p.ksize) * ES;
+        int tap = 0, ky = 0, kx = 0, c0b = 0, cbase = 0, c_in = 0, lk = 0;
         int a_vo[NP][2];
         auto set_tap = [&]() {
             const int tap_off = ((ky * p.W + kx) * p.in_cstride) * ES;
@@ -129,19 +131,25 @@ __global__ __launch_bounds__(768, 1) void conv_l12_kernel(const ConvK p) {
                 buffer_load16_lds(rs_in, smem + A_BASE + st * A_TILE + r * PART + (l + 4 * u) * 1024, a_vo[r][u], c0b);
         };
         auto advance = [&]() {
-            c0b += BKB;
+            c_in += BKB;
             ++lk;
-            if (c0b >= p.Cin * ES) {
-                c0b = 0;
+            bool moved = false;
+            if (c_in >= chb) {
+                c_in = 0;
                 ++tap;
-                if (++kx >= p.ksize) { kx = 0; ++ky; }
+                if (++kx >= p.ksize) {
+                    kx = 0;
+                    if (++ky >= p.ksize) { ky = 0; tap = 0; cbase += chb; }
+                }
+                moved = true;
             }
+            c0b = cbase + c_in;
             if (lk >= nk) {
 #pragma unroll
                 for (int j = 0; j < NP; ++j) a_mask[j][0] = a_mask[j][1] = 0;
                 tap = 0;
             }
-            if (c0b == 0 || lk >= nk) set_tap();
+            if (moved || lk >= nk) set_tap();
         };
         // weight pieces i0..i0+3 of K-tile T -> weight stage T & 1 (past the last K-tile: out of range = no traffic)
         auto issue_b = [&](int i0, int T) {

@@ -175,7 +175,9 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
     if (p.touch != 0) weight_touch(rs_wt, smem + 2 * STAGE, n0 * p.K * ES, 256 * p.K * ES, wave, 8, lane);
     const int nk = p.K / BK;
     // staging cursor: the K-tile whose regions are being issued (tap, byte offset of c0, byte offset of k in the weights)
-    int tap = 0, ky = 0, kx = 0, c0b = 0, ktb = 0, lk = 0;
+    // (canonical K order, common.h: 64-channel chunk -> tap -> channel; a K-tile of this kernel is one (chunk, tap))
+    const int chb = k_chunk_channels(p.Cin, p.ksize) * ES;
+    int tap = 0, ky = 0, kx = 0, c0b = 0, cbase = 0, c_in = 0, ktb = 0, lk = 0;
     int a_vo[NP];
     auto set_tap = [&]() {
         const int tap_off = ((ky * p.W + kx) * p.in_cstride) * ES;
@@ -193,13 +195,19 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
 #endif
     auto advance = [&]() {
         ktb += BKB;
-        c0b += BKB;
+        c_in += BKB;
         ++lk;
-        if (c0b >= p.Cin * ES) {
-            c0b = 0;
+        bool moved = false;
+        if (c_in >= chb) {                         // next tap of this chunk; after the last tap the next chunk
+            c_in = 0;
             ++tap;
-            if (++kx >= p.ksize) { kx = 0; ++ky; }
+            if (++kx >= p.ksize) {
+                kx = 0;
+                if (++ky >= p.ksize) { ky = 0; tap = 0; cbase += chb; }
+            }
+            moved = true;
         }
+        c0b = cbase + c_in;
         if (lk >= nk) {                            // past the last K-tile: keep the load count, move no bytes
 #pragma unroll
             for (int j = 0; j < NP; ++j) a_mask[j] = 0;
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
             for (int j = 0; j < 4; ++j) b_vo[j] = (int)0x80000000;
             tap = 0;
         }
-        if (c0b == 0 || lk >= nk) set_tap();
+        if (moved || lk >= nk) set_tap();
     };
     const int rowA = (wm * 32) * BKB, rowB = A_TILE + (wn * WCH) * BKB;
     const bool full = (m0 + BM <= p.M) && (n0 + 256 <= p.cout_store);

@@ -12,7 +12,7 @@
 // output never exists in HBM.  Cost: the 1-pixel halo ring of the 1x1 conv is recomputed (1.27x of 10 % of the FLOPs),
 // and tensors whose side is not a multiple of 16 (76, 52) have partially filled edge tiles.
 //
-// Numerics: every conv issues the same MFMAs (v_mfma_f32_16x16x32, K ascending: tap-major, natural channel order) on the
+// Numerics: every conv issues the same MFMAs (v_mfma_f32_16x16x32, K ascending in the canonical order of common.h: 64-channel block, tap, channel) on the
 // same 16-bit inputs as its conv_igemm kernel and the same fp32 epilogue -> bit-identical to the unfused path.
 #include <type_traits>
 
@@ -81,7 +81,7 @@ template <int C, int TY = RB_T> struct RbGeom {
     static constexpr int NF = C / 16;                  // output-channel fragments of a conv
     static constexpr int KS1 = C / 32;                 // MFMA k-steps of the 1x1 conv
     // The weights of both convs form ONE stream of equal steps of 64 input channels (2 MFMA k-steps x NF fragments x 1 KB):
-    // P steps of the 1x1 conv, then 9 * P steps of the 3x3 conv (tap-major).  They go through a 4-slot LDS ring, three
+    // P steps of the 1x1 conv, then 9 * P steps of the 3x3 conv (64-channel block, then tap: common.h).  They go through a 4-slot LDS ring, three
     // steps ahead of their use, with counted vmcnt waits -- an L2 round trip (~1 us under load) is longer than one step.
     static constexpr int STEP_BYTES = 2 * NF * 1024;
     static constexpr int P = KS1 / 2;                  // steps of the 1x1 conv
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
             auto read_frags = [&](int buf, int st, int kk) {              // all arguments are compile-time after unrolling
                 if ((RB_ABL & 32) && st > G::P) return;
                 const int ks = st - G::P;
-                const int tap = ks / G::P, cb = ks - tap * G::P;           // 64-channel block `cb` of tap `tap`
+                const int cb = ks / 9, tap = ks - cb * 9;                  // tap `tap` of 64-channel block `cb`: the canonical K order (common.h)
                 const int ky = tap / 3, kx = tap - ky * 3;
                 const char* const wst = ring + (st & (G::RING - 1)) * G::STEP_BYTES;
 #pragma unroll
@@ -348,8 +348,8 @@ __global__ __launch_bounds__(64 * RB_WAVES, C == 64 ? 4 : 2) void resblock_kerne
             read_frags(0, G::P, 0);                                        // step P landed at the top of the tile
 #pragma unroll
             for (int st = G::P; st < G::NSTEPS; ++st) {
-                if (st == G::P + 3 * G::P) RB_POINT(5);                    // taps 0..2 done
-                if (st == G::P + 6 * G::P) RB_POINT(6);                    // taps 3..5 done
+                if (st == G::P + 3 * G::P) RB_POINT(5);                    // a third of the stream done
+                if (st == G::P + 6 * G::P) RB_POINT(6);                    // two thirds
                 if (RB_LATE && !RES_LDS && st == S0) load_res();
                 // sched_barrier: hipcc otherwise re-serialises the pipeline into "read one fragment, wait for it, 4 MFMAs"
                 // (fewer live registers, but every wait exposes the LDS latency); pinned, the 8-12 reads of the next
@@ -527,14 +527,15 @@ int resblock_launch(int dtype, int c, const void* in, int n, int side, int in_cs
 // ------------------------------------------------------------------------------------------------ weight packing
 // (cout, cin, k, k) float32 -> MFMA A fragments, natural K order, chunked output-channel layout (same as csp_stage.hip):
 //   out[((s*NREP + j)*64 + lane)*8 + e] = W[ch][ci][tap], ch = ((j>>1)*4 + (i>>2))*8 + (j&1)*4 + (i&3), i = lane & 15,
-//   k-step s = tap*(cin/32) + cb, ci = 32*cb + 8*(lane>>4) + e
+//   k-step s = 2*(cb64*k*k + tap) + half (64-channel block cb64 -> tap -> half: common.h), ci = 32*(2*cb64 + half) + 8*(lane>>4) + e
 template <int DT>
 __global__ void rb_pack_frag_kernel(const float* __restrict__ w, typename Elem<DT>::type* __restrict__ out, int cout, int cin, int kk) {
     const int nrep = cout / 16, cbs = cin / 32, total = cout * cin * kk;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int e = idx & 7, lane = (idx >> 3) & 63, r = idx >> 9;
         const int j = r % nrep, s = r / nrep;
-        const int tap = s / cbs, cb = s - tap * cbs;
+        // canonical K order (common.h): 64-channel block -> tap -> the block's two 32-channel k-steps
+        const int step = s >> 1, cb64 = step / kk, tap = step - cb64 * kk, cb = cb64 * 2 + (s & 1);
         const int i = lane & 15, gg = lane >> 4;
         const int ch = ((j >> 1) * 4 + (i >> 2)) * 8 + (j & 1) * 4 + (i & 3);
         const int ci = 32 * cb + 8 * gg + e;

@@ -692,6 +692,7 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
     // a float32 head (as a plain launch or as the tail of an LDS pair) also fills its cells' slots of the objectness array
     ConvObjDesc od{};
     const ConvObjDesc* odp = nullptr;
+    int obj_head = -1;
     {
         const Op* ho = op.out_f32 ? &op : (chain && chain->lds_pair && h->ops[chain->tail[0]].out_f32 ? &h->ops[chain->tail[0]] : nullptr);
         if (ho)
@@ -700,9 +701,14 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
                     od.obj = (float*)(h->act + h->obj_off) + (size_t)img0 * h->cells_per_img * 4;
                     od.nf = 5 + h->cfg.num_classes; od.cells_per_img = h->cells_per_img; od.cell_base = h->cell_base[i];
                     odp = &od;
-                    h->obj_n[i] = img0 + n;
+                    obj_head = i;
+                    h->obj_n[i] = -1;                     // (valid again once the launch below has been enqueued)
                 }
     }
+    auto launched = [&](int rc) {                          // the side array counts only after a successful enqueue
+        if (rc == Y4_OK && obj_head >= 0) h->obj_n[obj_head] = img0 + n;
+        return rc;
+    };
     if (chain && chain->lds_pair) {
         const Op& to = h->ops[chain->tail[0]];
         const Layer& TL = h->layers[to.conv];
@@ -716,7 +722,7 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
             pd.cout = 2 * TL.d.cout; pd.split = to.split;
             pd.fin2 = buf_ptr(h, to.out2, img0); pd.fin2_cstride = to.out2.cstride; pd.fin2_coff = to.out2.coff;
         }
-        return conv2d_launch(&d, h->act + h->zero_off, s, nullptr, &pd, odp);
+        return launched(conv2d_launch(&d, h->act + h->zero_off, s, nullptr, &pd, odp));
     }
     if (chain && chain->alt_of >= 0) {
         // this op (64 -> 64) feeds the conv over Concatenate([its output, route]) in registers; its own output is not stored
@@ -756,7 +762,7 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
         cd.fin = buf_ptr(h, last->out, img0); cd.fin_cstride = last->out.cstride; cd.fin_coff = last->out.coff;
         return conv2d_launch(&d, h->act + h->zero_off, s, &cd);
     }
-    return conv2d_launch(&d, h->act + h->zero_off, s, nullptr, nullptr, odp);
+    return launched(conv2d_launch(&d, h->act + h->zero_off, s, nullptr, nullptr, odp));
 }
 
 int run_decode_nms(y4_handle h, int n, float iou_thr, float score_thr, float* boxes, float* scores, float* classes,
@@ -807,7 +813,7 @@ int run_decode_nms(y4_handle h, int n, float iou_thr, float score_thr, float* bo
 extern "C" {
 
 const char* y4_last_error(void) { return g_err; }
-const char* y4_version(void) { return "yolo4hip 0.1 (gfx950)"; }
+const char* y4_version(void) { return "yolo4hip 0.2 (gfx950)"; }
 
 int y4_create(const y4_config* cfg, y4_handle* out) {
     Y4_REQUIRE(cfg && out, Y4_EINVAL, "y4_create: null argument");
@@ -891,9 +897,13 @@ int y4_bind_workspace(y4_handle h, void* act_dev, size_t act_bytes, void* wts_de
     h->counts_clean = false;
     h->wts = (char*)wts_dev;
     h->weights_ready = false;
-    Y4_CHECK_HIP(hipMemset(h->act + h->zero_off, 0, ZERO_PAGE_BYTES));
-    Y4_CHECK_HIP(hipMemset(h->act + h->status_off, 0, 256));
-    Y4_CHECK_HIP(hipMemset(h->act + h->splitk_off, 0, SPLITK_CNT_BYTES));      // split-K tile counters: zero between launches
+    // The WHOLE activation workspace starts as zeros (round 5; once per bind, ~1 ms per 3 GB): the zero page, the NMS status word and
+    // the split-K tile counters (zero between launches) need it, and no result can then depend on what the caller's memory held
+    // before -- a workspace from a caching allocator carries the previous owner's tensors.
+    Y4_CHECK_HIP(hipMemset(h->act, 0, h->act_bytes));
+    // ... and it HAS happened when this returns: the caller may use the handle on any stream next, and a non-blocking stream (every
+    // torch.cuda.Stream is one) does not order itself behind the null stream the memset ran on
+    Y4_CHECK_HIP(hipStreamSynchronize(nullptr));
     return Y4_OK;
 }
 
@@ -1187,7 +1197,7 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
         if (cold) {
             float total = 0.f;
             for (int i = 0; i < reps; ++i) {
-                if (l2_flush_launch(h->wts, flush_bytes, h->act + h->zero_off, s) != Y4_OK) return -2.f;
+                if (l2_flush_launch(h->wts, flush_bytes, h->act + h->scratch_off, s) != Y4_OK) return -2.f;
                 if (hipEventRecord(e0, s) != hipSuccess) return -2.f;
                 run_both(oi, ne, chained);
                 float ms = 0.f;
