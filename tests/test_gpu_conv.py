@@ -104,6 +104,72 @@ def test_all_tiles_agree(dtype):
     assert ran >= 4 and (dtype == "f32" or ran32 >= 2)
 
 
+HALO_CASES = [   # (side, cin, cout, n, act, residual, in_pad, out_pad): 3x3 stride-1 convs of the plan's 19^2 / 38^2 / 76^2 stages and smaller
+    (19, 128, 256, 3, "leaky", False, (0, 0), (0, 0)),        # one band = the whole image
+    (38, 64, 128, 2, "mish", True, (0, 0), (0, 0)),           # ragged bands (10 + 10 + 10 + 8 rows at 384 pixels), residual Add
+    (38, 256, 256, 1, "mish", True, (64, 0), (0, 128)),       # four chunks: the halo double buffer turns over; channel slices
+    (76, 128, 128, 1, "leaky", False, (0, 0), (0, 0)),        # pitch 80; 320-pixel bands of 4 rows
+    (13, 128, 128, 5, "mish", False, (0, 0), (128, 0)),       # 416 / 32: pitch 16
+    (26, 192, 256, 2, "leaky", False, (0, 64), (0, 0)),       # three chunks
+    (24, 64, 128, 2, "mish", True, (0, 0), (0, 0)),           # one chunk (Cin = 64); two bands of 12 rows
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("case", HALO_CASES, ids=lambda c: f"h{c[0]}_{c[1]}to{c[2]}_n{c[3]}")
+def test_halo_tiles_vs_oracle_and_bit_identical(case, dtype):
+    """conv_halo_kernel (tile ids with schedule code 20: the input halo tile staged once per 64-channel chunk, nine taps from LDS)
+    against the oracle's conv_block (reference custom_layers.py:5-31, :44) AND bit for bit against the implicit-GEMM kernel's
+    built-in tile: same MFMAs in the same canonical K order (csrc/common.h)."""
+    import ctypes as C
+    from yolo4hip import ext
+    from yolo4hip.weights import ConvWeights
+    side, cin, cout, n, act, use_res, in_pad, out_pad = case
+    rng = np.random.default_rng(1000 + side + cin)
+    x = quantize(rng.standard_normal((n, side, side, cin)).astype(np.float32), dtype)
+    cw = make_conv_weights(rng, cout, cin, 3)
+    cwq = ConvWeights(w=quantize(cw.w, dtype), bn=cw.bn, bias=cw.bias)
+    res = quantize(rng.standard_normal((n, side, side, cout)).astype(np.float32), dtype) if use_res else None
+    base, _ = run_conv_gpu(x, cwq, 3, 1, act, dtype, residual=res, in_pad=in_pad, out_pad=out_pad)
+    want = _ref(x, cwq, 3, 1, act, res, False)
+    atol, rtol = TOL[dtype]
+    assert np.all(np.abs(base - want) <= atol + rtol * np.abs(want))
+    lib = ext.load()
+    ran = 0
+    for tile in range(1, lib.y4_conv_tile_count() + 1):
+        cfg = (C.c_int32 * 6)()
+        ext.check(lib.y4_conv_tile_desc(tile, cfg))
+        if cfg[5] != 20:
+            continue
+        try:
+            got, full = run_conv_gpu(x, cwq, 3, 1, act, dtype, residual=res, in_pad=in_pad, out_pad=out_pad, tile=tile)
+        except ext.Y4Error as e:
+            assert e.code == -22          # this band geometry does not fit the layer: refused, not computed wrongly
+            continue
+        ran += 1
+        err = np.abs(got - want)
+        assert np.all(err <= atol + rtol * np.abs(want)), f"halo tile {tile}: max err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+        assert np.array_equal(got, base), f"halo tile {tile} differs from the implicit-GEMM kernel: {np.abs(got - base).max():.3e}"
+        if out_pad[0]:
+            assert np.all(full[..., :out_pad[0]] == -5.0)
+        if out_pad[1]:
+            assert np.all(full[..., out_pad[0] + cout:] == -5.0)
+    assert ran >= 1, "no halo tile fits this case"
+
+
+def test_halo_tiles_refuse_what_they_cannot_run():
+    """A halo tile id on a 1x1 conv, a stride-2 conv, float32, or a map wider than the tile is refused (Y4_EINVAL), never mis-run."""
+    from yolo4hip import ext
+    rng = np.random.default_rng(0)
+    for k, stride, side, cin, cout, dtype in ((1, 1, 19, 128, 128, "bf16"), (3, 2, 38, 128, 128, "bf16"), (3, 1, 19, 128, 128, "f32"),
+                                              (3, 1, 19, 32, 128, "bf16")):
+        x = quantize(rng.standard_normal((1, side, side, cin)).astype(np.float32), dtype)
+        cw = make_conv_weights(rng, cout, cin, k)
+        with pytest.raises(ext.Y4Error) as e:
+            run_conv_gpu(x, cw, k, stride, "mish", dtype, tile=51)
+        assert e.value.code == -22
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_splitk_fixup_sees_this_launch_partial_sums(dtype):
     """The split-K fix-up has no cache maintenance any more (round 4: agent-scope accesses + "my stores have completed" instead of

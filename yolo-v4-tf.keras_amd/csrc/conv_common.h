@@ -65,6 +65,11 @@ struct ConvK {
     int ksplit;
     float* part;                   // [ksplit][tiles][MREP * NREP][threads] float4
     int* split_cnt;                // [tiles], zero between launches
+    // halo tiles (conv_halo_kernel.h): an output tile is a band of h_rows full image rows (h_bands bands per image; grid_m = N * h_bands),
+    // its input a halo tile of (h_rows + 2) x h_pitch LDS rows per 64-channel chunk (h_pitch = W + 2 rounded up to 8)
+    int h_rows, h_bands, h_pitch;
+    int h_abl;                     // experiments only (HALO_ABL: timing ablations of conv_halo_kernel, wrong results when != 0)
+    FastDiv h_div_pitch, h_div_bands;
 };
 
 template <int CPR> __device__ __forceinline__ int swz(int row) {
@@ -326,9 +331,11 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvK& p, f32x4 (&acc)[
 // XL (an LDS pair's head): the packed tile goes to LDS in the K loop's pixel-operand layout instead (conv_epilogue_impl), nothing to
 // memory here -- the row's swizzle term is the lane's (rows 16 apart share their low bits), so a chunk's LDS address is a per-lane base
 // plus a compile-time row stride.
-template <int DT, int MREP, int NREP, int ACT, bool RES, int GW, bool XL = false>
+// LIM: the tile's pixel rows end at `m_limit` (a band of image rows that does not fill the MFMA tile, conv_halo_kernel.h): rows past it
+// get an out-of-range offset -- their residual loads read zeros, their stores are dropped by the descriptor's bounds check.
+template <int DT, int MREP, int NREP, int ACT, bool RES, int GW, bool XL = false, bool LIM = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvK& p, f32x4 (&acc)[MREP][NREP], const float* sc, const float* sh, int mrow,
-                                                   int chw, int fg, char* xl = nullptr, int xrow = 0, int xpanel = 0) {
+                                                   int chw, int fg, char* xl = nullptr, int xrow = 0, int xpanel = 0, int m_limit = 0) {
     using E = Elem<DT>;
     constexpr int EPC = E::EPC, ES = 16 / EPC, NC = NREP / 2, SPC = 8 / EPC;      // SPC: 16-byte stores per 8-channel chunk
     constexpr bool FAST = (DT != Y4_F32);
@@ -352,7 +359,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& p, f32x4 (&acc)[
     const __amdgpu_buffer_rsrc_t rsr = make_rsrc(RES ? p.res : p.out, RES ? p.res_bytes : p.out_bytes);
     const int laner = (p.res_coff + chw + fg * 8) * ES, rowr = p.res_cstride * ES;
     auto load_res = [&](int i) {
-        const int o = (mrow + i * ROWS) * rowr + laner;
+        const int o = (LIM && mrow + i * ROWS >= m_limit) ? (int)0x80000000 : (mrow + i * ROWS) * rowr + laner;
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -380,7 +387,8 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& p, f32x4 (&acc)[
             }
         }
         const int m = mrow + i * ROWS;
-        const int o1 = m * row1 + lane1, o2 = m * row2 + lane2;
+        const bool dead = LIM && m >= m_limit;
+        const int o1 = dead ? (int)0x80000000 : m * row1 + lane1, o2 = dead ? (int)0x80000000 : m * row2 + lane2;
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -440,6 +448,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP]
     float sc[NREP * 4], sh[NREP * 4];
     conv_epilogue_tables<NREP, GW>(p, chw, fg, sc, sh);
     conv_epilogue_with<DT, MREP, NREP, XL, GW>(p, acc, sc, sh, mrow, m_limit, chw, fg, full, xl, xrow, xpanel);
+}
+
+// A tile whose channel block is full but whose pixel rows end at m_limit (halo tiles): the fast epilogue with dropped rows where it
+// applies (16-byte stores of the compute dtype, Mish / LeakyReLU), else the general one.  Same arithmetic either way.
+template <int DT, int MREP, int NREP>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvK& p, f32x4 (&acc)[MREP][NREP], int mrow, int m_limit, int chw, int fg, bool ch_full) {
+    float sc[NREP * 4], sh[NREP * 4];
+    conv_epilogue_tables<NREP, 4>(p, chw, fg, sc, sh);
+    if (Y4_FAST_EPI && ch_full && p.fast_epi && p.act != Y4_ACT_LINEAR && (p.act == Y4_ACT_MISH || !p.res)) {
+        if (p.act == Y4_ACT_LEAKY) conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_LEAKY, false, 4, false, true>(p, acc, sc, sh, mrow, chw, fg, nullptr, 0, 0, m_limit);
+        else if (p.res) conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_MISH, true, 4, false, true>(p, acc, sc, sh, mrow, chw, fg, nullptr, 0, 0, m_limit);
+        else conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_MISH, false, 4, false, true>(p, acc, sc, sh, mrow, chw, fg, nullptr, 0, 0, m_limit);
+        return;
+    }
+    conv_epilogue_with<DT, MREP, NREP>(p, acc, sc, sh, mrow, m_limit, chw, fg, false);
 }
 
 // LDS pair: the head conv's tile, kept in LDS by the XL epilogue, goes to its HBM view(s) (lane re-reads the chunks it

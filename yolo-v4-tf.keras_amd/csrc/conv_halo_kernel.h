@@ -1,0 +1,205 @@
+// conv_halo_kernel.h -- 3x3 stride-1 'same' conv (the reference's conv() unit, custom_layers.py:5-31, with its Add / concat-slice
+// epilogue) with the INPUT HALO TILE STAGED ONCE PER 64-CHANNEL CHUNK and all nine taps run from it (round 5; VERDICT r4 item 3,
+// north_star's "LDS-staged input tiles").
+//
+// conv_igemm_kernel re-stages the activation rows of every tap: per K-tile of a 192 x 256 tile 24 KB of pixels + 32 KB of weights go
+// L2 -> LDS, and the LDS-DMA stream is what bounds its K loop (7 one-KB pieces per wave and K-tile at
+// 100-185 cycles of issue each, 36 % MFMA-busy).  Here an output tile is a BAND of R full image rows of one image -- R * W <= BM
+// consecutive pixels of the NHWC tensor -- and its input for one chunk of 64 channels is the band plus one row above and below:
+// (R + 2) rows of P = roundup(W + 2, 8) LDS rows of 128 bytes (column 0 and columns > W are the conv's zero padding: out-of-range
+// lanes of the descriptor load, no traffic).  In that image tap (ky, kx) of pixel (y, x) is the row  (y + ky) P + (x + kx): the
+// tile's own row plus a constant, so the nine K-tiles of a chunk read the SAME LDS tile at nine shifts and only the weights
+// (BN x 128 bytes per tap) stream.  Per nine K-tiles of a 384 x 128 tile at 38 x 38: 60 KB of pixels + 144 KB of weights instead
+// of 432 + 144 (same FLOPs as 192 x 256's 216 + 288): 2.5x fewer LDS-DMA pieces per FLOP.
+//
+// K order: the canonical one of common.h (64-channel chunk -> tap -> channel), i.e. exactly what every other conv kernel sums in
+// since round 5 -- same MFMAs (v_mfma_f32_16x16x32), same operands, same order: results are BIT-IDENTICAL to conv_igemm_kernel's.
+//
+// LDS: [halo tile, chunk c & 1][halo tile, (c + 1) & 1][weights, K-tile kt & 1][weights, (kt + 1) & 1][touch scratch].  One barrier
+// per K-tile (tap), as in the 2-stage ring: it proves this K-tile's weights (issued one K-tile ago) and -- at tap 0 -- this chunk's
+// halo tile (issued piece by piece during the previous chunk's taps) have landed for every wave, and that every wave is done with
+// the buffers the next loads overwrite.  Rows are XOR-swizzled by their low three bits like conv_igemm_kernel's; P % 8 == 0 keeps
+// a vertical tap shift from changing them, so a lane keeps three fragment base addresses per pixel fragment (kx = 0, 1, 2).
+#pragma once
+#include "conv_common.h"
+#include "conv_tiles.h"
+
+namespace y4 {
+
+constexpr int HALO_KA_MAX = 9;     // halo-tile pieces (1 KB) a wave stages per chunk, at most (one per tap)
+
+template <int DT, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 1) void conv_halo_kernel(const ConvK p) {
+    static_assert(DT != Y4_F32, "halo tiles: 16-bit dtypes");
+    constexpr int NT = 64 * WM * WN, NW = WM * WN;
+    constexpr int ES = 2, BKB = 128, CPR = 8, EPC = 8;
+    constexpr int RPI = NT / CPR;                       // weight rows staged per block-wide load instruction
+    constexpr int B_IT = BN / RPI;
+    constexpr int WPX = BM / WM, WCH = BN / WN, MREP = WPX / 16, NREP = WCH / 16;
+    constexpr int WSTAGE = BN * BKB;
+    static_assert(BN % RPI == 0 && WPX % 16 == 0 && WCH % 32 == 0, "tile shape");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    asm volatile("" ::"s"(p.H), "s"(p.W), "s"(p.Cin), "s"(p.K), "s"(p.in_cstride), "s"(p.in_coff), "s"(p.grid_m), "s"(p.grid_n), "s"(p.in_bytes),
+                 "s"(p.wt_bytes), "s"(p.h_rows), "s"(p.h_bands), "s"(p.h_pitch), "s"(p.touch));
+
+    // ---- XCD-aware tile mapping (as conv_igemm_kernel: an XCD's blocks take a contiguous run of tiles, channel tile fastest)
+    const int nwg = p.grid_m * p.grid_n;
+    int t;
+    {
+        const int b = blockIdx.x, qq = nwg >> 3, rr = nwg & 7, xcd = b & 7, idx = b >> 3;
+        t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int tile_m = (int)fastdiv((uint32_t)t, p.div_gridn), tile_n = t - tile_m * p.grid_n;
+    const int n0 = tile_n * BN;
+    const int img = (int)fastdiv((uint32_t)tile_m, p.h_div_bands), band = tile_m - img * p.h_bands;
+    const int R = p.h_rows, P = p.h_pitch, W = p.W, H = p.H;
+    const int y0 = band * R;
+    const int rows_here = H - y0 < R ? H - y0 : R;
+    const int npx = rows_here * W;                      // valid pixels of the tile: m_base .. m_base + npx
+    const int m_base = (img * H + y0) * W;
+    const int AROWS = (R + 2) * P, ABYTES = AROWS * BKB, APIECES = AROWS >> 3;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    char* const lds_wt = smem + 2 * ABYTES;
+
+    // ---- staging set-up.  Halo tile: piece u = 8 LDS rows; this wave stages pieces wave, wave + NW, ...; lane (row u*8 + lane/8,
+    //      physical chunk lane%8) copies logical chunk (lane%8) ^ (row & 7) of image pixel (y0 - 1 + row / P, row % P - 1).
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(p.wt, p.wt_bytes);
+    int a_vo[HALO_KA_MAX];
+#pragma unroll
+    for (int k = 0; k < HALO_KA_MAX; ++k) {
+        const int u = wave + k * NW;
+        const int r = u * 8 + (lane >> 3), q = lane & 7;
+        const int yy = (int)fastdiv((uint32_t)r, p.h_div_pitch), xx = r - yy * P;
+        const int iy = y0 - 1 + yy, ix = xx - 1;
+        const bool ok = u < APIECES && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        a_vo[k] = ok ? (((img * H + iy) * W + ix) * p.in_cstride + p.in_coff + ((q ^ (r & 7)) * EPC)) * ES : (int)0x80000000;
+    }
+    // Weights: as conv_igemm_kernel (row permutation of the chunked accumulator layout, source-side swizzle)
+    const int q = tid % CPR, r0 = tid / CPR;
+    int b_off[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        const int row = r0 + j * RPI;
+        const int wb = row / WCH, pr = row - wb * WCH;
+        const int jn = pr >> 4, i = pr & 15, g = i >> 2, r = i & 3;
+        const int ch = chunk_channel(n0 + wb * WCH, jn >> 1, g) + (jn & 1) * 4 + r;
+        b_off[j] = (ch * p.K + ((q ^ swz<CPR>(row)) * EPC)) * ES;
+    }
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
+    auto stage_a = [&](int k, int buf, int cbyte) {      // piece k of this wave's share of the chunk at channel byte offset cbyte
+        buffer_load16_lds(rs_in, smem + buf * ABYTES + (wave + k * NW) * 1024, a_vo[k], cbyte);
+    };
+    auto stage_w = [&](int st, int ktb) {
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) buffer_load16_lds(rs_wt, lds_wt + st * WSTAGE + wave_lds + j * (NT * 16), b_off[j], ktb);
+    };
+
+    if (p.touch != 0) weight_touch(rs_wt, lds_wt + 2 * WSTAGE, n0 * p.K * ES, BN * p.K * ES, wave, NW, lane);
+
+    // ---- fragment addresses.  Pixel fragment i of this lane = tile pixel wm*WPX + 16 i + frow = image position (y, x) of the band;
+    //      its halo row for tap (ky, kx) is (y + ky) P + x + kx; the three kx variants are kept (the row's swizzle bits move with kx),
+    //      ky adds a multiple of 8 rows.  Pixels past the band (the MFMA tile's padding) read pixel 0's rows; they are never stored.
+    const int frow = lane & 15, fg = lane >> 4;
+    int abase[3][MREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        int pix = wm * WPX + i * 16 + frow;
+        pix = pix < npx ? pix : 0;
+        const int y = (int)fastdiv((uint32_t)pix, p.div_wo), x = pix - y * W;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int r = y * P + x + kx;                     // tap row ky = 0 of this pixel
+            abase[kx][i] = r * BKB + ((fg ^ (r & 7)) << 4);
+        }
+    }
+    int xo[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) xo[kk] = frow * BKB + (((kk * 4 + fg) ^ swz<CPR>(frow)) * 16);
+    const char* const lds_w = lds_wt + (wn * WCH) * BKB;
+
+    f32x4 acc[MREP][NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = p.Cin >> 6;
+    const int my_pieces = (APIECES - wave + NW - 1) / NW;     // pieces of a halo tile this wave stages (wave-uniform)
+    // ---- prologue: chunk 0's halo tile and K-tile 0's weights
+#pragma unroll
+    for (int k = 0; k < HALO_KA_MAX; ++k)
+        if (k < my_pieces) stage_a(k, 0, 0);
+    stage_w(0, 0);
+    int ktb = BKB;                                      // byte offset in a weight row of the NEXT K-tile to stage
+    const int row_shift = P * BKB;                      // one halo row down
+    for (int c = 0; c < nchunks; ++c) {
+        const int abuf = (c & 1) * ABYTES;
+        const bool more_chunks = c + 1 < nchunks;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            if (p.h_abl & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else
+            wait_vmcnt_then_barrier<0>();
+            const int st = (c + tap) & 1;           // stage parity: K-tile index c*9 + tap; 9 is odd, so the parity alternates with c as well
+            const char* const sa = smem + abuf + ky * row_shift;
+            const char* const sw = lds_w + st * WSTAGE;
+            // the next K-tile's weights and one piece of the next chunk's halo tile: a whole K-tile to land (issued in front of the
+            // fragment reads: behind them measured equal on the 96 x 64 wave tiles and 8 % slower on the 96 x 32 one)
+            if ((tap < 8 || more_chunks) && !(p.h_abl & 1)) { stage_w(st ^ 1, ktb); ktb += BKB; }
+            if (more_chunks && tap < my_pieces && !(p.h_abl & 2)) stage_a(tap, (c + 1) & 1, (c + 1) * BKB);
+            u32x4 xf[2][MREP], wf[2][NREP];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) xf[kk][i] = *(const u32x4*)(sa + (abase[kx][i] ^ (kk << 6)));
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) wf[kk][j] = *(const u32x4*)(sw + j * 16 * BKB + xo[kk]);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                    for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc[i][j], wf[kk][j], xf[kk][i]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+
+    // ---- epilogue (conv_common.h): rows past the band are dropped
+    const bool ch_full = n0 + BN <= p.cout_store;
+    conv_epilogue_rows<DT, MREP, NREP>(p, acc, m_base + wm * WPX + frow, m_base + npx, n0 + wn * WCH, fg, ch_full);
+}
+
+// ------------------------------------------------------------------------------------------- launch
+template <int DT, int BM, int BN, int WM, int WN>
+static int launch_halo_cfg(const ConvK& k, hipStream_t stream) {
+    const size_t lds = halo_lds_bytes(k.h_rows, k.h_pitch, BN);
+    Y4_REQUIRE(lds <= 160 * 1024, Y4_EINVAL, "conv2d: halo tile needs %zu bytes of LDS", lds);
+    Y4_REQUIRE(((k.h_rows + 2) * k.h_pitch / 8 + WM * WN - 1) / (WM * WN) <= HALO_KA_MAX, Y4_EINVAL, "conv2d: halo tile has too many pieces per wave");
+    auto kern = conv_halo_kernel<DT, BM, BN, WM, WN>;
+    static PerDeviceOnce once;
+    if (const uint64_t bit = once.due()) {
+        Y4_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        once.mark(bit);
+    }
+    hipLaunchKernelGGL(kern, dim3(k.grid_m * k.grid_n), dim3(64 * WM * WN), lds, stream, k);
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
+}
+
+template <int DT>
+static int launch_halo(int bm, int bn, const ConvK& k, hipStream_t s) {
+    if (bm == 384 && bn == 128) return launch_halo_cfg<DT, 384, 128, 4, 2>(k, s);
+    if (bm == 320 && bn == 128) return launch_halo_cfg<DT, 320, 128, 4, 2>(k, s);
+    if (bm == 192 && bn == 256) return launch_halo_cfg<DT, 192, 256, 2, 4>(k, s);
+    if (bm == 192 && bn == 128) return launch_halo_cfg<DT, 192, 128, 2, 4>(k, s);
+    set_error("conv2d: no halo tile %d x %d", bm, bn);
+    return Y4_EINVAL;
+}
+
+}  // namespace y4

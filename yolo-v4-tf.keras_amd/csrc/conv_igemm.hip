@@ -20,6 +20,15 @@ int conv_p8_launch(int dtype, int bm, int nst, const ConvK& k, hipStream_t s) {
     return Y4_EINVAL;
 }
 
+int conv_halo_launch_bf16(int bm, int bn, const ConvK& k, hipStream_t s);
+int conv_halo_launch_f16(int bm, int bn, const ConvK& k, hipStream_t s);
+int conv_halo_launch(int dtype, int bm, int bn, const ConvK& k, hipStream_t s) {
+    if (dtype == Y4_BF16) return conv_halo_launch_bf16(bm, bn, k, s);
+    if (dtype == Y4_F16) return conv_halo_launch_f16(bm, bn, k, s);
+    set_error("conv2d: halo tiles are 16-bit only");
+    return Y4_EINVAL;
+}
+
 int conv_tile_count() { return kNumTiles; }
 
 // the weight touch of conv_common.h is on unless Y4_NO_WEIGHT_TOUCH=1 (A/B measurements only: results are the same)
@@ -148,6 +157,18 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
                d->cin, cout_pad);
     k.grid_m = (k.M + tc.bm - 1) / tc.bm;
     k.grid_n = (int)((round_up(d->cout, 8) + tc.bn - 1) / tc.bn);
+    if (tc.nst == 20) {
+        // halo tiles (conv_halo_kernel.h): 3x3 stride-1 convs whose band geometry fits the LDS; plain launches with 16-byte stores
+        HaloPlan hp{};
+        Y4_REQUIRE(d->dtype != Y4_F32 && d->ksize == 3 && d->stride == 1 && d->cin % 64 == 0 && !pair && k.ntail == 0 && !split_e && !d->upsample &&
+                       !d->out_f32 && !d->out2 && halo_plan(tc.bm, tc.bn, d->h, d->w, &hp),
+                   Y4_EINVAL, "conv2d: tile %d (halo, %d x %d) does not fit this conv (3x3 stride 1, 16-bit, cin %% 64 == 0, %d x %d map)", tile,
+                   tc.bm, tc.bn, d->h, d->w);
+        k.h_rows = hp.rows; k.h_bands = hp.bands; k.h_pitch = hp.pitch;
+        k.h_div_pitch = fastdiv_make((uint32_t)hp.pitch); k.h_div_bands = fastdiv_make((uint32_t)hp.bands);
+        k.grid_m = d->n * hp.bands;
+        { static const int abl = [] { const char* e = getenv("HALO_ABL"); return e ? atoi(e) : 0; }(); k.h_abl = abl; }
+    }
     Y4_REQUIRE((int64_t)k.grid_n * tc.bn <= cout_pad, Y4_EINVAL, "conv2d: tile %d overruns the packed weight rows", tile);
     k.div_gridn = fastdiv_make((uint32_t)k.grid_n);
     if (split_e) {

@@ -650,8 +650,10 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
     return Y4_OK;
 }
 
-// the phased kernel (conv_p8_kernel.h) lives in its own translation units (conv_p8_<dt>.hip)
+// the phased kernel (conv_p8_kernel.h) lives in its own translation units (conv_p8_<dt>.hip), the halo kernel
+// (conv_halo_kernel.h) in conv_halo_<dt>.hip
 int conv_p8_launch(int dtype, int bm, int nst, const ConvK& k, hipStream_t s);
+int conv_halo_launch(int dtype, int bm, int bn, const ConvK& k, hipStream_t s);
 
 // plain tiles of one dtype (one translation unit per dtype: conv_igemm_<dt>.hip)
 template <int DT>
@@ -662,6 +664,7 @@ static int launch_plain(int tile, const ConvK& k, hipStream_t s) {
         if constexpr (DT == Y4_F32 && !f32_tile(id)) break;                                   \
         else if constexpr (DT == Y4_F32 && nst == 32) break;                                  \
         else if constexpr (nst == 8 || nst == 9 || nst == 10) return conv_p8_launch(DT, bm, nst, k, s); \
+        else if constexpr (nst == 20) return conv_halo_launch(DT, bm, bn, k, s);              \
         else return launch_cfg<DT, bm, bn, wm, wn, bkb, nst>(k, s);
     switch (tile) { Y4_TILES(Y4_TILE_CASE) }
     set_error("conv2d: tile id %d is not available for this dtype", tile);

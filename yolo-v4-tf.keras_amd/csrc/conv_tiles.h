@@ -9,7 +9,8 @@ struct TileCfg {
 };
 // id, BM (pixels), BN (channels), WM, WN (wave grid), BKB (bytes of K per LDS row), NST (ring stages, 2..7; 12 = the staggered
 // 2-stage schedule, 32 = 2 stages with the 32x32x16 MFMA; conv_p8_kernel.h: 8 = staggered wave groups, 9 = software-pipelined;
-// 10 = the producer / consumer kernel of conv_l12_kernel.h).
+// 10 = the producer / consumer kernel of conv_l12_kernel.h; 20 = a HALO tile of conv_halo_kernel.h: 3x3 stride-1 convs, BM pixels = a
+// band of full image rows, the input halo tile staged once per 64-channel chunk).
 // The table is also what tests and the autotuner sweep through y4_conv_desc.tile.
 #define Y4_TILES(X)            \
     X(1, 128, 128, 2, 2, 128, 2)  \
@@ -61,7 +62,11 @@ struct TileCfg {
     X(47, 128, 64, 4, 1, 128, 4)  \
     X(48, 32, 64, 2, 2, 128, 7)   \
     X(49, 32, 64, 2, 2, 128, 5)   \
-    X(50, 64, 64, 2, 2, 128, 4)
+    X(50, 64, 64, 2, 2, 128, 4)   \
+    X(51, 384, 128, 4, 2, 128, 20) \
+    X(52, 192, 256, 2, 4, 128, 20) \
+    X(53, 192, 128, 2, 4, 128, 20) \
+    X(54, 320, 128, 4, 2, 128, 20)
 
 #define Y4_TILE_ROW(id, bm, bn, wm, wn, bkb, nst) {bm, bn, wm, wn, bkb, nst},
 static const TileCfg kTiles[] = {Y4_TILES(Y4_TILE_ROW)};
@@ -70,7 +75,8 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 constexpr int F32_TILES = 12;
 // ... and the deep rings (round 4: what a single image's latency-bound K loops need)
 constexpr int DEEP_TILE0 = 43;
-inline constexpr bool f32_tile(int id) { return id <= F32_TILES || id >= DEEP_TILE0; }
+constexpr int DEEP_TILE1 = 50;
+inline constexpr bool f32_tile(int id) { return id <= F32_TILES || (id >= DEEP_TILE0 && id <= DEEP_TILE1); }
 
 // the tiles that sum in the 32x32x16 MFMA's order (bit-identical among themselves, not with the others)
 inline bool mfma32_tile(int tile) { return tile >= 1 && tile <= kNumTiles && kTiles[tile - 1].nst == 32; }
@@ -92,6 +98,24 @@ inline int tile_split_e(int tile) { return tile >= 100 ? tile / 100 : 0; }
 // a well-formed tile id (0 = heuristic)
 inline bool tile_id_ok(int tile) {
     return tile >= 0 && tile_base(tile) <= kNumTiles && tile_split_e(tile) <= SPLITK_MAX_E && (tile < 100 || splitk_tile(tile_base(tile)));
+}
+
+// Halo tiles (conv_halo_kernel.h): the band geometry of a BM-pixel tile on an H x W feature map -- rows per band (balanced over the
+// image), bands per image, LDS pitch of a halo row -- and the LDS it needs with BN output channels per tile.
+inline bool halo_tile(int tile) { return tile >= 1 && tile <= kNumTiles && kTiles[tile - 1].nst == 20; }
+struct HaloPlan { int rows, bands, pitch; };
+inline size_t halo_lds_bytes(int rows, int pitch, int bn) { return (size_t)2 * (rows + 2) * pitch * 128 + (size_t)2 * bn * 128 + 256; }
+inline bool halo_plan(int bm, int bn, int H, int W, HaloPlan* out) {
+    if (W < 1 || H < 1 || W > bm) return false;
+    int rows = bm / W;
+    if (rows > H) rows = H;
+    const int bands = (H + rows - 1) / rows;
+    rows = (H + bands - 1) / bands;                       // balanced: the last band is at most one row short per band
+    const int pitch = (W + 2 + 7) / 8 * 8;
+    if (halo_lds_bytes(rows, pitch, bn) > 160 * 1024) return false;
+    if ((int64_t)H * W * 4 < (int64_t)bands * bm * 3) return false;      // less than 3/4 of the MFMA tiles' rows would be pixels
+    *out = HaloPlan{rows, bands, pitch};
+    return true;
 }
 
 // chain heads: the tiles with one wave column over 64 channels
