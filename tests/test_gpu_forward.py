@@ -328,6 +328,31 @@ def test_stem_fusion_is_bit_identical(dtype, size, n):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("size,n", [(352, 2), (608, 1)])
+def test_halo_tile_as_lds_pair_head_is_bit_identical(dtype, size, n):
+    """The 3x3+Add -> next block's 1x1 runs of the 38^2 stage (convs 42-43 .. 56-57, reference custom_layers.py:34-44) with the 192 x 256
+    HALO tile (id 52, csrc/conv_halo_kernel.h) forced as head of the LDS pair: the head's tile stays in LDS over the dead halo buffers and
+    the 1x1 conv runs from it.  Heads, the runs' outputs and the detections equal the unfused path bit for bit."""
+    cfg, plan, ws, imgs, eng = _setup(size, 3, n, dtype, seed=8)
+    heads = eng.forward_heads(imgs)
+    taps = (43, 45, 47, 49, 51, 53, 55, 57, 58)
+    ref = {i: eng.conv_output(i, n) for i in taps}
+    base = eng.predict(imgs, with_indices=True)
+    eng.set_chain_fusion(True)
+    tiles = [0] * 110
+    for head in range(42, 57, 2):
+        tiles[head] = -(52 + 1000 * 51)          # run tile 52 (halo pair head); own tile when not fused: the 384 x 128 halo tile
+    eng.set_tiles(tiles)
+    for a, b in zip(heads, eng.forward_heads(imgs)):
+        assert np.array_equal(a, b)
+    for i in taps:
+        assert np.array_equal(ref[i], eng.conv_output(i, n)), i
+    for a, b in zip(base, eng.predict(imgs, with_indices=True)):
+        assert np.array_equal(a, b)
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("size,n", [(96, 5), (160, 3), (416, 2), (608, 1)])
 def test_chain_fusion_is_bit_identical(dtype, size, n):
     """3x3+Add -> 1x1 (-> 1x1 over the concat) and CSP-pair -> 1x1 runs as one kernel each: a chained conv issues the

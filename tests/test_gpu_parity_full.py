@@ -51,8 +51,8 @@ def _head_errors(heads, ref_heads, rows):
 # to 8 (bf16) / 11 (fp16) mantissa bits), on raw head logits of std ~1.3.  Measured on MI355X over rounds 2-5 (every run appends to
 # gpurun_out/parity_measured.jsonl; the last ones are kept under profiles/):
 #   bf16, 608/80 batch 32: mean |err| 0.062-0.075, 99.9 % quantile 0.27-0.34, max 0.52-0.59; 89-94 % of the oracle's 100
-#         detections per image matched by (box, class); score delta of the matched ones: 90 % below 0.03, max 0.04-0.10
-#   fp16, 416/3 batch 64: mean 0.0063-0.0075, 99.9 % quantile 0.033-0.042; 98-100 % matched, score delta <= 0.007
+#         detections per image matched by (box, class); score delta of the matched ones: 90 % below 0.024-0.034, max 0.04-0.10
+#   fp16, 416/3 batch 64: mean 0.0063-0.0075, 99.9 % quantile 0.033-0.042; 98-100 % matched, score delta <= 0.007 (90 % below 0.0035)
 # Bounds (round 5, VERDICT r4 item 4: measured + ~15 % instead of + 40 %):
 #   * the BULK figures -- mean, 99.9 % quantile, matched fraction (3 detections of 100 below the worst measured image), the 90 %
 #     quantile of the score delta -- are tight;
@@ -64,8 +64,8 @@ def _head_errors(heads, ref_heads, rows):
 # oracle's heads, and within near-ties for the fp32 path: tests/test_gpu_forward.py).
 BUDGET = {
     #        mean |err|, 99.9 % quantile, min matched fraction, max score delta (tail), 90 % quantile of the score delta (bulk)
-    "bf16": (0.087, 0.40, 0.86, 0.30, 0.045),
-    "f16": (0.0087, 0.049, 0.96, 0.02, 0.006),
+    "bf16": (0.087, 0.40, 0.86, 0.30, 0.040),
+    "f16": (0.0087, 0.049, 0.96, 0.02, 0.0042),
 }
 
 

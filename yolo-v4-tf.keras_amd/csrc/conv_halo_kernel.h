@@ -28,7 +28,9 @@ namespace y4 {
 
 constexpr int HALO_KA_MAX = 9;     // halo-tile pieces (1 KB) a wave stages per chunk, at most (one per tap)
 
-template <int DT, int BM, int BN, int WM, int WN>
+// PAIR: an LDS pair (conv_igemm_kernel.h) with this conv as head -- BN = Cout: the finished tile stays in LDS in the K loop's
+// pixel-operand layout and the following 1x1 conv (p.tail[0], output view p.fin) runs from it in the same kernel.
+template <int DT, int BM, int BN, int WM, int WN, bool PAIR = false>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_halo_kernel(const ConvK p) {
     static_assert(DT != Y4_F32, "halo tiles: 16-bit dtypes");
     constexpr int NT = 64 * WM * WN, NW = WM * WN;
@@ -170,18 +172,89 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_halo_kernel(const ConvK 
         }
     }
 
-    // ---- epilogue (conv_common.h): rows past the band are dropped
-    const bool ch_full = n0 + BN <= p.cout_store;
-    conv_epilogue_rows<DT, MREP, NREP>(p, acc, m_base + wm * WPX + frow, m_base + npx, n0 + wn * WCH, fg, ch_full);
+    const int mrow = m_base + wm * WPX + frow, m_limit = m_base + npx;
+    if constexpr (PAIR) {
+        // ---- LDS pair (as conv_igemm_kernel's): the head's tile -> LDS panels [BN/64][BM rows][128 B] over the dead halo buffers, the
+        // tail's weights through two stages behind them, the same fragment reads and K order as the 1x1 conv's own kernel.  Rows
+        // past the band hold whatever their (never stored) accumulators held.
+        constexpr int XPANEL = BM * 128, NK2 = BN / 64, XBYTES = NK2 * XPANEL, W2STAGE = BN * 128;
+        __syncthreads();                                   // every wave is done with the K loop's buffers
+        char* const xl = smem;
+        const int xrow = wm * WPX + frow, chw = wn * WCH;
+        int b2_off[B_IT];
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const int row = r0 + j * RPI;
+            const int wb = row / WCH, pr = row - wb * WCH;
+            const int jn = pr >> 4, i = pr & 15, g = i >> 2, r = i & 3;
+            const int ch = chunk_channel(wb * WCH, jn >> 1, g) + (jn & 1) * 4 + r;
+            b2_off[j] = (ch * p.tail_k + ((q ^ swz<CPR>(row)) * EPC)) * ES;
+        }
+        const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(p.tail[0].w, p.tail_w_bytes);
+        auto stage_w2 = [&](int buf, int kt) {
+#pragma unroll
+            for (int j = 0; j < B_IT; ++j)
+                buffer_load16_lds(rs_w2, smem + XBYTES + buf * W2STAGE + wave_lds + j * (NT * 16), b2_off[j], kt * BKB);
+        };
+        stage_w2(0, 0);                                    // its round trip hides under the head's epilogue
+        conv_epilogue<DT, MREP, NREP, true>(p, acc, mrow, m_limit, chw, fg, true, xl, xrow, XPANEL);
+        __syncthreads();                                   // X complete
+        f32x4 acc2[MREP][NREP];
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nk2 = p.tail_k >> 6;
+        int xo2[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) xo2[kk] = frow * BKB + (((kk * 4 + fg) ^ swz<CPR>(frow)) * 16);
+        for (int kt = 0; kt < nk2; ++kt) {
+            wait_vmcnt_then_barrier<0>();
+            if (kt + 1 < nk2) stage_w2((kt + 1) & 1, kt + 1);
+            const char* sx = xl + (p.tail_panel0 + kt) * XPANEL + (wm * WPX) * BKB;
+            const char* sw2 = smem + XBYTES + (kt & 1) * W2STAGE + (wn * WCH) * BKB;
+            u32x4 xf2[2][MREP], wf2[2][NREP];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) xf2[kk][i] = *(const u32x4*)(sx + i * 16 * BKB + xo2[kk]);
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) wf2[kk][j] = *(const u32x4*)(sw2 + j * 16 * BKB + xo2[kk]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                    for (int j = 0; j < NREP; ++j) Mma<DT>::run(acc2[i][j], wf2[kk][j], xf2[kk][i]);
+        }
+        ConvK p2 = p;
+        p2.scale = p.tail[0].scale; p2.shift = p.tail[0].shift; p2.act = p.tail_act; p2.res = nullptr;
+        p2.out = p.fin; p2.out_cstride = p.fin_cstride; p2.out_coff = p.fin_coff;
+        p2.cout_store = p.tail[0].cout; p2.upsample = 0; p2.out_f32 = p.pair >> 1;
+        p2.split = p.tail_split; p2.out2 = p.fin2; p2.out2_cstride = p.fin2_cstride; p2.out2_coff = p.fin2_coff;
+        p2.fast_epi = p.fast_tail; p2.out_bytes = p.fin_bytes; p2.out2_bytes = p.fin2_bytes;
+        conv_epilogue_rows<DT, MREP, NREP>(p2, acc2, mrow, m_limit, chw, fg, BN <= p2.cout_store);
+        if (p.store_x) pair_store_tile<DT, MREP, NREP>(p, xl, xrow, XPANEL, mrow, m_limit, chw, fg);
+    } else {
+        // ---- epilogue (conv_common.h): rows past the band are dropped
+        const bool ch_full = n0 + BN <= p.cout_store;
+        conv_epilogue_rows<DT, MREP, NREP>(p, acc, mrow, m_limit, n0 + wn * WCH, fg, ch_full);
+    }
 }
 
 // ------------------------------------------------------------------------------------------- launch
-template <int DT, int BM, int BN, int WM, int WN>
+template <int DT, int BM, int BN, int WM, int WN, bool PAIR = false>
 static int launch_halo_cfg(const ConvK& k, hipStream_t stream) {
-    const size_t lds = halo_lds_bytes(k.h_rows, k.h_pitch, BN);
+    size_t lds = halo_lds_bytes(k.h_rows, k.h_pitch, BN);
     Y4_REQUIRE(lds <= 160 * 1024, Y4_EINVAL, "conv2d: halo tile needs %zu bytes of LDS", lds);
     Y4_REQUIRE(((k.h_rows + 2) * k.h_pitch / 8 + WM * WN - 1) / (WM * WN) <= HALO_KA_MAX, Y4_EINVAL, "conv2d: halo tile has too many pieces per wave");
-    auto kern = conv_halo_kernel<DT, BM, BN, WM, WN>;
+    if (PAIR) {
+        const size_t lds_pair = (size_t)(BN / 64) * BM * 128 + (size_t)2 * BN * 128;      // tile panels + two weight stages of the tail
+        static_assert(!PAIR || (BN / 64) * BM * 128 + 2 * BN * 128 <= 160 * 1024, "LDS budget of the pair phase");
+        lds = lds > lds_pair ? lds : lds_pair;
+    }
+    auto kern = conv_halo_kernel<DT, BM, BN, WM, WN, PAIR>;
     static PerDeviceOnce once;
     if (const uint64_t bit = once.due()) {
         Y4_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -194,6 +267,11 @@ static int launch_halo_cfg(const ConvK& k, hipStream_t stream) {
 
 template <int DT>
 static int launch_halo(int bm, int bn, const ConvK& k, hipStream_t s) {
+    if (k.pair) {
+        if (bm == 192 && bn == 256) return launch_halo_cfg<DT, 192, 256, 2, 4, true>(k, s);
+        set_error("conv2d: no halo tile %d x %d heads an LDS pair", bm, bn);
+        return Y4_EINVAL;
+    }
     if (bm == 384 && bn == 128) return launch_halo_cfg<DT, 384, 128, 4, 2>(k, s);
     if (bm == 320 && bn == 128) return launch_halo_cfg<DT, 320, 128, 4, 2>(k, s);
     if (bm == 192 && bn == 256) return launch_halo_cfg<DT, 192, 256, 2, 4>(k, s);

@@ -160,7 +160,7 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
     if (tc.nst == 20) {
         // halo tiles (conv_halo_kernel.h): 3x3 stride-1 convs whose band geometry fits the LDS; plain launches with 16-byte stores
         HaloPlan hp{};
-        Y4_REQUIRE(d->dtype != Y4_F32 && d->ksize == 3 && d->stride == 1 && d->cin % 64 == 0 && !pair && k.ntail == 0 && !split_e && !d->upsample &&
+        Y4_REQUIRE(d->dtype != Y4_F32 && d->ksize == 3 && d->stride == 1 && d->cin % 64 == 0 && k.ntail == 0 && !split_e && !d->upsample &&
                        !d->out_f32 && !d->out2 && halo_plan(tc.bm, tc.bn, d->h, d->w, &hp),
                    Y4_EINVAL, "conv2d: tile %d (halo, %d x %d) does not fit this conv (3x3 stride 1, 16-bit, cin %% 64 == 0, %d x %d map)", tile,
                    tc.bm, tc.bn, d->h, d->w);
