@@ -18,7 +18,7 @@ By default `--in-flight 2`: step i runs on HIP stream / activation workspace i %
 GPU; every step of a block still completes inside the block's bracket); `--in-flight 1` = every step on one stream, and
 `single_stream_value` in the line is that rate measured in the same process.
 Schedule (tile per launch, fusion kernels on / off -- every choice gives the same bits): the tuned one that ships for the
-shape (yolo4hip/schedules/, the kernel mix profiles/r04 was profiled with) if there is one, else a one-off autotune on this
+shape (yolo4hip/schedules/, the kernel mix profiles/r05 was profiled with) if there is one, else a one-off autotune on this
 box; `--retune` forces the autotune, `--load-tiles` a file; `schedule` in the line says which ran.
 `roofline` is for the dominant kernel family (the conv kernels: convs 2..109 with the stem fusion, else 1..109):
 algorithmic conv FLOPs of one step / its summed device time, measured with HIP events recorded on the launch stream
@@ -159,7 +159,7 @@ def committed_traffic(args, fused_stem, chained, staged, res_mask, tiles):
     per-layer tile ids as the profiled run (`tiles.json` next to the profile).  Counters cannot be read from inside the
     process: the figure is NOT measured by this run, `traffic_source` says where it comes from."""
     reasons = []
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", rnd, "hbm_traffic.json")
         try:
             prof = json.load(open(path))
@@ -236,7 +236,7 @@ def parse_args(argv):
     ap.add_argument("--load-tiles", default=None, help="use tile ids from this JSON file instead of autotuning")
     ap.add_argument("--retune", action="store_true",
                     help="autotune on this box even when a tuned schedule ships with the package for this shape "
-                         "(yolo4hip/schedules/: the headline shape's is the tile set profiles/r03 was profiled with)")
+                         "(yolo4hip/schedules/: the headline shape's is the tile set profiles/r05 was profiled with)")
     ap.add_argument("--subbatch", type=int, default=0,
                     help="images per sub-batch for the early layers (0 = whole batch); sub-batching and workspace aliasing exclude each "
                          "other (y4_set_subbatch refuses), so a run with --subbatch uses the plain, un-aliased workspace")

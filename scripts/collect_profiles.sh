@@ -1,8 +1,8 @@
 #!/bin/bash
-# Collects the measurement set committed under profiles/r04 (run on the GPU box, from the repo root), ONCE per round:
-#   rm -rf gpurun_out/r4set                 # LOCALLY first: gpurun merges into gpurun_out/
+# Collects the measurement set committed under profiles/r05 (run on the GPU box, from the repo root), ONCE per round:
+#   rm -rf gpurun_out/r5set                 # LOCALLY first: gpurun merges into gpurun_out/
 #   gpurun --timeout 2700 -- 'Y4_COLLECT_TILES=yolo-v4-tf.keras_amd/yolo4hip/schedules/608_80_32_bf16.json bash scripts/collect_profiles.sh'
-# Produces in gpurun_out/r4set (all from ONE call on one box):
+# Produces in gpurun_out/r5set (all from ONE call on one box):
 #   bench.json + tiles.json        the default bench (two batches in flight; incl. cpu_baseline) and its tuned tile / fusion set
 #   bench_single_stream.json       the same tile set with --in-flight 1 (HIP events inside the timed blocks)
 #   in_flight_sweep.txt            scripts/two_batches.py 1 / 2 / 3
@@ -15,7 +15,7 @@
 #   bench_cfg5.json / bench_cfg2.json   BASELINE.json configs 5 and 2
 set -x
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/r4set; rm -rf $O; mkdir -p $O/pmc
+O=gpurun_out/r5set; rm -rf $O; mkdir -p $O/pmc
 SMI="rocm-smi --showclocks --showpower --showtemp --showperflevel --showmaxpower"
 $SMI > $O/smi_idle.txt 2>&1
 # the schedule of the whole set: $Y4_COLLECT_TILES (a schedule file, e.g. scripts/instep_select.py's) if given, else a fresh autotune on THIS box;

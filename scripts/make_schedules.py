@@ -24,6 +24,7 @@ out = sys.argv[1]
 shapes = sys.argv[2:] or ["416_80_32_bf16", "416_80_1_bf16", "608_80_1_bf16", "608_80_1_f32", "416_80_1_f32"]
 os.makedirs(out, exist_ok=True)
 os.environ["YOLO4HIP_CACHE"] = tempfile.mkdtemp(prefix="y4sched_")
+os.environ.setdefault("YOLO4HIP_LATENCY", "1")      # the batch-1 schedules that ship carry split-K ids (tested against the oracle)
 flats = {}
 for key in shapes:
     side, ncls, batch, dtype = key.split("_")

@@ -150,7 +150,10 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_halo_kernel(const ConvK 
             const char* const sa = smem + abuf + ky * row_shift;
             const char* const sw = lds_w + st * WSTAGE;
             // the next K-tile's weights and one piece of the next chunk's halo tile: a whole K-tile to land (issued in front of the
-            // fragment reads: behind them measured equal on the 96 x 64 wave tiles and 8 % slower on the 96 x 32 one)
+            // fragment reads: behind them measured equal on the 96 x 64 wave tiles and 8 % slower on the 96 x 32 one).
+            // Also measured and not kept: reading the NEXT tap's k-step-0 pixel fragments under this tap's k-step-1 MFMAs (legal: the
+            // halo tile does not change with the tap) -- no gain on the 96 x 32 wave tile, which has the registers for it (105 us
+            // against 104-107), and 44-288 bytes of scratch per lane on the 96 x 64 ones, which run at 254-256 registers as they are.
             if ((tap < 8 || more_chunks) && !(p.h_abl & 1)) { stage_w(st ^ 1, ktb); ktb += BKB; }
             if (more_chunks && tap < my_pieces && !(p.h_abl & 2)) stage_a(tap, (c + 1) & 1, (c + 1) * BKB);
             u32x4 xf[2][MREP], wf[2][NREP];
