@@ -335,13 +335,15 @@ def test_halo_tile_as_lds_pair_head_is_bit_identical(dtype, size, n):
     the 1x1 conv runs from it.  Heads, the runs' outputs and the detections equal the unfused path bit for bit."""
     cfg, plan, ws, imgs, eng = _setup(size, 3, n, dtype, seed=8)
     heads = eng.forward_heads(imgs)
-    taps = (43, 45, 47, 49, 51, 53, 55, 57, 58)
+    taps = (22, 24, 26, 28, 30, 32, 34, 36, 37, 43, 45, 47, 49, 51, 53, 55, 57, 58)
     ref = {i: eng.conv_output(i, n) for i in taps}
     base = eng.predict(imgs, with_indices=True)
     eng.set_chain_fusion(True)
     tiles = [0] * 110
     for head in range(42, 57, 2):
         tiles[head] = -(52 + 1000 * 51)          # run tile 52 (halo pair head); own tile when not fused: the 384 x 128 halo tile
+    for head in range(21, 36, 2):                # ... and the 76^2 stage's runs (Cout = 128) with the 384 x 128 / 320 x 128 halo tiles as heads
+        tiles[head] = -((51 if size == 352 else 54) + 1000 * 8)
     eng.set_tiles(tiles)
     for a, b in zip(heads, eng.forward_heads(imgs)):
         assert np.array_equal(a, b)

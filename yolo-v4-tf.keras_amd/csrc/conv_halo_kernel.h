@@ -272,6 +272,8 @@ template <int DT>
 static int launch_halo(int bm, int bn, const ConvK& k, hipStream_t s) {
     if (k.pair) {
         if (bm == 192 && bn == 256) return launch_halo_cfg<DT, 192, 256, 2, 4, true>(k, s);
+        if (bm == 384 && bn == 128) return launch_halo_cfg<DT, 384, 128, 4, 2, true>(k, s);
+        if (bm == 320 && bn == 128) return launch_halo_cfg<DT, 320, 128, 4, 2, true>(k, s);
         set_error("conv2d: no halo tile %d x %d heads an LDS pair", bm, bn);
         return Y4_EINVAL;
     }

@@ -682,7 +682,9 @@ static int launch_fused(int tile, const ConvK& k, hipStream_t s) {
                 Y4_PAIR_CASE(24, 160, 128, 2, 2) Y4_PAIR_CASE(25, 192, 128, 2, 2) Y4_PAIR_CASE(29, 112, 128, 1, 4)
                 Y4_PAIR_CASE(13, 128, 256, 2, 4) Y4_PAIR_CASE(19, 192, 256, 2, 4) Y4_PAIR_CASE(21, 96, 256, 2, 4)
                 Y4_PAIR_CASE(22, 160, 256, 2, 4) Y4_PAIR_CASE(38, 384, 128, 4, 2)
-                case 52: return conv_halo_launch(DT, 192, 256, k, s);        // the halo tile as head (conv_halo_kernel.h)
+                case 51: return conv_halo_launch(DT, 384, 128, k, s);        // the halo tiles as heads (conv_halo_kernel.h)
+                case 52: return conv_halo_launch(DT, 192, 256, k, s);
+                case 54: return conv_halo_launch(DT, 320, 128, k, s);
             }
 #undef Y4_PAIR_CASE
         }

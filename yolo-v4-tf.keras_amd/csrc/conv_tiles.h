@@ -122,9 +122,9 @@ inline bool halo_plan(int bm, int bn, int H, int W, HaloPlan* out) {
 inline bool chain_tile(int tile) { return tile == 3 || tile == 4 || tile == 15; }
 
 // LDS-pair heads: 128-byte K rows, 2 stages, one channel tile over all of Cout (128 or 256), tile + tail stages in LDS
-// (52: the 192 x 256 halo tile, conv_halo_kernel.h)
+// (51, 52, 54: the halo tiles of conv_halo_kernel.h -- 384 x 128 and 320 x 128 for Cout = 128, 192 x 256 for Cout = 256)
 inline bool pair_tile(int tile) {
-    switch (tile) { case 1: case 8: case 20: case 24: case 25: case 29: case 13: case 19: case 21: case 22: case 38: case 52: return true; }
+    switch (tile) { case 1: case 8: case 20: case 24: case 25: case 29: case 13: case 19: case 21: case 22: case 38: case 51: case 52: case 54: return true; }
     return false;
 }
 
