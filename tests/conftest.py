@@ -38,7 +38,7 @@ def _gpu_unavailable_reason():
 # everything that only compares the HIP path with itself.  Rank = position of the first matching (file, test-name prefix) rule.
 GPU_ORDER = [    # (file, test-name prefix, rank); the first matching rule counts
     ("test_gpu_ref_fixtures.py", "", 0),                                       # the reference's own Python under the TF stand-in
-    ("test_gpu_parity_full.py", "test_headline_config_bf16_vs_oracle", 1),      # BASELINE config 3
+    ("test_gpu_parity_full.py", "test_headline_config_vs_oracle", 1),           # BASELINE config 3 (bf16; fp16 beside it)
     ("test_gpu_parity_full.py", "test_config5_416_b64_f16_real_batch", 2),      # BASELINE config 5
     ("test_gpu_forward.py", "test_fp32_forward_and_nms_parity", 3),             # BASELINE config 2 (608 / 80 / batch 1 fp32) and smaller
     ("test_gpu_parity_full.py", "test_shipped_schedule_keeps_the_bits", 20),    # (a self-comparison: with the others of its kind)

@@ -53,6 +53,8 @@ def _head_errors(heads, ref_heads, rows):
 #   bf16, 608/80 batch 32: mean |err| 0.062-0.075, 99.9 % quantile 0.27-0.34, max 0.52-0.59; 89-94 % of the oracle's 100
 #         detections per image matched by (box, class); score delta of the matched ones: 90 % below 0.024-0.034, max 0.04-0.10
 #   fp16, 416/3 batch 64: mean 0.0063-0.0075, 99.9 % quantile 0.033-0.042; 98-100 % matched, score delta <= 0.007 (90 % below 0.0035)
+#   fp16, 608/80 batch 32: mean 0.0078-0.0095, 99.9 % quantile 0.035-0.043, max 0.069; 97-100 % matched, score delta <= 0.008
+#         (90 % below 0.0035), box delta <= 0.0013 -- eight to ten times closer to the oracle than bf16 at the same MFMA rate
 # Bounds (round 5, VERDICT r4 item 4: measured + ~15 % instead of + 40 %):
 #   * the BULK figures -- mean, 99.9 % quantile, matched fraction (3 detections of 100 below the worst measured image), the 90 %
 #     quantile of the score delta -- are tight;
@@ -65,7 +67,7 @@ def _head_errors(heads, ref_heads, rows):
 BUDGET = {
     #        mean |err|, 99.9 % quantile, min matched fraction, max score delta (tail), 90 % quantile of the score delta (bulk)
     "bf16": (0.087, 0.40, 0.86, 0.30, 0.040),
-    "f16": (0.0087, 0.049, 0.96, 0.02, 0.0042),
+    "f16": (0.011, 0.050, 0.96, 0.02, 0.0042),
 }
 
 
@@ -80,14 +82,28 @@ def _check_budget(dtype, errs, agree, q90, rows):
         assert ds < min(ds_b, 0.5 * worst_logit + 1e-3), f"image {rows[j]}: score delta {ds:.4f} exceeds what the largest logit error {worst_logit:.3f} allows"
 
 
-def test_headline_config_bf16_vs_oracle():
-    """BASELINE.json config 3: 608x608, 80 classes, bf16, batch 32, stem + chain + stage fusions and autotune on -- the
-    exact schedule bench.py times -- against oracle.forward (fp32) on 4 images of the batch (indices 0, 9, 18, 31)."""
-    import torch
+_ORACLE_CACHE = {}
+
+
+def _headline_oracle(size, ncls, rows, ws, imgs, cfg):
+    """The fp32 oracle's heads and detections for the headline batch's sample images (computed once per process: ~10 s of CPU)."""
     from oracle import forward as OF, decode_nms as OD
+    key = (size, ncls, tuple(rows))
+    if key not in _ORACLE_CACHE:
+        ref_heads = OF.yolo_model_forward(imgs[rows], ws, ncls)
+        _ORACLE_CACHE[key] = (ref_heads, OD.inference_from_heads(ref_heads, ncls, cfg["anchors"], cfg["xyscale"], size))
+    return _ORACLE_CACHE[key]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_headline_config_vs_oracle(dtype):
+    """BASELINE.json config 3: 608x608, 80 classes, batch 32, stem + chain + stage fusions and autotune on -- the schedule family
+    bench.py times -- against oracle.forward (fp32) on 4 images of the batch (indices 0, 9, 18, 31).  bf16 is what BASELINE names;
+    fp16 is the same kernels at the same MFMA rate with three more mantissa bits (measured side by side)."""
+    import torch
     from yolo4hip import weights as W
     from yolo4hip.plan import build_plan
-    size, ncls, n, dtype = 608, 80, 32, "bf16"
+    size, ncls, n = 608, 80, 32
     ws = W.synth_weights(build_plan(size, ncls), seed=0)
     imgs = W.synth_images(n, size, seed=0)
     cfg, eng = _engine(size, ncls, n, dtype, ws)
@@ -99,16 +115,16 @@ def test_headline_config_bf16_vs_oracle():
     eng.autotune(n, reps=2)
     outs = [o.cpu().numpy() for o in eng.predict_device(dev)]
     heads = [h.cpu().numpy() for h in eng.heads_device(n)]
+    assert all(np.isfinite(h).all() for h in heads), "non-finite head logits (fp16 overflow?)"
     rows = [0, 9, 18, 31]
-    ref_heads = OF.yolo_model_forward(imgs[rows], ws, ncls)
+    ref_heads, (rb, rs, rc, rv, ri) = _headline_oracle(size, ncls, rows, ws, imgs, cfg)
     errs = _head_errors(heads, ref_heads, rows)
-    rb, rs, rc, rv, ri = OD.inference_from_heads(ref_heads, ncls, cfg["anchors"], cfg["xyscale"], size)
     boxes, scores, classes, valid, kept = outs
     agree = [detection_agreement(kept[r], classes[r], scores[r], boxes[r], valid[r], ri[j], rc[j], rs[j], rb[j], rv[j])
              for j, r in enumerate(rows)]
     q90 = [score_delta_quantile(kept[r], classes[r], scores[r], valid[r], ri[j], rc[j], rs[j], rv[j]) for j, r in enumerate(rows)]
-    _record("headline_608_80_bf16_b32", {"head_err_mean_q999_max": errs, "agreement_frac_dscore_dbox": agree, "dscore_q90": q90,
-                                         "valid": [int(valid[r]) for r in rows], "ref_valid": [int(v) for v in rv]})
+    _record(f"headline_608_80_{dtype}_b32", {"head_err_mean_q999_max": errs, "agreement_frac_dscore_dbox": agree, "dscore_q90": q90,
+                                             "valid": [int(valid[r]) for r in rows], "ref_valid": [int(v) for v in rv]})
     _check_budget(dtype, errs, agree, q90, rows)
     assert sum(int(v) for v in rv) > 40, "the synthetic heads must give NMS real work"
     eng.close()
