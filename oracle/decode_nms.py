@@ -34,7 +34,7 @@ F32 = np.float32
 def sigmoid(x):
     # NOTE: exact float32 1/(1+exp(-x)).  TensorFlow's CPU kernel for tf.sigmoid is Eigen's clamped rational `logistic`
     # approximation, which differs from this by a few ulp: scores within ~1e-7 relative of the 0.3 cut can fall on the other
-    # side in TensorFlow.  Identity of kept indices is therefore defined against THIS restatement.
+    # side in TensorFlow.  Identity of kept indices is therefore defined against THIS restatement (LABNOTES.md section 2).
     x = np.asarray(x, dtype=F32)
     return (F32(1.0) / (F32(1.0) + np.exp(-x))).astype(F32)
 

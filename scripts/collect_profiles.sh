@@ -48,19 +48,18 @@ python scripts/pmc_kernels.py $O/pmc_kernels.json $O/pmc/pass3 $O/pmc/pass4 $O/p
 python scripts/mfma_util.py $O/pmc_kernels.json - $O/mfma_util.json $O/sq_wait_breakdown.json > $O/mfma_util.txt
 python bench.py --size 416 --classes 3 --batch 64 --dtype f16 --no-cpu-baseline --no-latency > $O/bench_cfg5.json 2>/dev/null
 python bench.py --batch 1 --dtype f32 --no-cpu-baseline --no-latency --steps 50 > $O/bench_cfg2.json 2>/dev/null
-# round 4: the microbenchmark and the in-kernel traces behind DESIGN.md sections 4.0a / 4.2a, and the part-tile A/B of section 4.1c
-scratch/ubench/mish_mfma > $O/ubench_mish_mfma.txt 2>&1
-[ -f scratch/libyolo4hip_cstr_all.so ] && YOLO4HIP_LIB=scratch/libyolo4hip_cstr_all.so python scripts/stage_trace.py > $O/stage_trace.txt 2>&1
-[ -f scratch/libyolo4hip_sdtr2.so ] && YOLO4HIP_LIB=scratch/libyolo4hip_sdtr2.so python scripts/stem_trace.py > $O/stem_trace.txt 2>&1
-[ -f scratch/libyolo4hip_rbtr128.so ] && YOLO4HIP_LIB=scratch/libyolo4hip_rbtr128.so python scripts/res_trace.py > $O/res_trace_128.txt 2>&1
-[ -f scratch/libyolo4hip_rbtr64.so ] && YOLO4HIP_LIB=scratch/libyolo4hip_rbtr64.so python scripts/res_trace.py > $O/res_trace_64.txt 2>&1
+# round 5: fp16 at the headline shape, the halo tiles against the implicit-GEMM tiles layer by layer, the determinism hunt
+python bench.py --dtype f16 --no-cpu-baseline --no-latency > $O/bench_608_80_32_f16.json 2>/dev/null
+python bench.py --dtype f16 --no-cpu-baseline --no-latency --in-flight 1 > $O/bench_608_80_32_f16_single_stream.json 2>/dev/null
+python scripts/halo_bench.py > $O/halo_bench_bf16.txt 2>&1
+python scripts/halo_bench.py --dtype f16 > $O/halo_bench_f16.txt 2>&1
+timeout 600 python scripts/determinism_hunt.py --sweep --iters 500 > $O/determinism_hunt.txt 2>&1
 # one image: the kernel timeline of a step on the shipped latency schedules (rocprofv3 --kernel-trace), bf16 and fp32
 for dt in bf16 f32; do
   rocprofv3 --kernel-trace --output-format csv -d $O/b1_$dt -- python3 bench.py --batch 1 --dtype $dt --no-cpu-baseline --no-latency --in-flight 1 --steps 40 --warmup 5 --blocks 1 > $O/b1_$dt.json 2> $O/b1_$dt.err
   python scripts/step_timeline.py $(ls $O/b1_$dt/*/*kernel_trace.csv | head -1) > $O/b1_${dt}_timeline.txt 2>&1
   rm -rf $O/b1_$dt
 done
-for v in 0 1 0 1; do Y4_RB_PARTS=$v python bench.py --no-cpu-baseline --no-latency --in-flight 1 --load-tiles $O/tiles.json --steps 60 --blocks 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('Y4_RB_PARTS=$v one stream', d['value'], 'img/s, conv family', d['roofline']['kernel_ms_per_step'], 'ms, backbone', d['roofline']['backbone_wall']['one_stream'])"; done > $O/resblock_parts.txt 2>&1
 find $O -name "*.csv" -size +20M -delete
 find $O -name "*agent_info.csv" -delete
 ls -la $O $O/stats/* | head -40

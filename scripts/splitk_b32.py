@@ -1,6 +1,6 @@
 """Experiment: what would split-K ids (and the cold-timed tuner that comes with y4_set_splitk) buy at the HEADLINE shape, batch 32?
 Prints images/s one stream and two in flight for the shipped schedule and for a schedule tuned with split-K allowed.  A split launch sums
-in another fp32 order, so such a schedule is not in the bit-identical set: measured, not shipped."""
+in another fp32 order, so such a schedule is not in the bit-identical set (LABNOTES.md section 4.7): measured, not shipped."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "yolo-v4-tf.keras_amd")); sys.path.insert(0, ROOT)

@@ -1,6 +1,6 @@
 """Per-layer tile sweep inside a ONE-image step: the shipped latency schedule with every conv of one class (ksize, cin, cout) forced onto a
 candidate tile id (split-K ids allowed), step time of 3 x 100 synchronised-at-the-end predicts, and the difference to the shipped schedule
-per layer of the class -- the layer runs cold, in its place in the step (this is what showed a split costing 40-120 us
+per layer of the class -- the layer runs cold, in its place in the step (LABNOTES.md section 4.7: this is what showed a split costing 40-120 us
 per layer before its fence was removed).
 usage: tile_sweep.py <bf16|f32> <ksize> <cin> <cout> <tile id> [<tile id> ...]      e.g.  tile_sweep.py f32 3 512 1024 48 49 148 149 249"""
 import json, os, sys, time

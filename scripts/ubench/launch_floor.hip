@@ -1,4 +1,4 @@
-// launch_floor.hip -- what a dependent chain of tiny kernels costs per launch on this GPU / runtime:
+// launch_floor.hip -- what a dependent chain of tiny kernels costs per launch on this GPU / runtime (LABNOTES.md section 4.7):
 //   empty:      no arguments read, nothing done
 //   args:       a 512-byte by-value struct, one field of its LAST 64 bytes read (the kernarg fetch: one scalar-cache miss per launch)
 //   args+load:  the same, then one dependent global load through a pointer from the struct and one store (two serial round trips,

@@ -1,4 +1,4 @@
-// MFMA || Mish co-issue microbenchmark for gfx950 (what bounds csp_stage_kernel).
+// MFMA || Mish co-issue microbenchmark for gfx950 (what bounds csp_stage_kernel, LABNOTES.md section 4.1b).
 // One 512-thread workgroup per CU (2 waves per SIMD).  Per iteration a wave issues 32 v_mfma_f32_16x16x32_bf16 (8 accumulators x
 // 4 k-steps) and the BN + Mish + bf16 pack of the PREVIOUS iteration's 8 accumulators (32 values per lane), the packed result
 // being the next iteration's B operand (the register chain of the stage kernel).

@@ -1,7 +1,7 @@
 """GPU parity at BASELINE.json's real configurations against the oracle, and of the device-side BatchNorm fold.
 
   * config 3 (608x608, 80 classes, bf16, fusions + autotune on): head logits and detections of 4 images of the batch vs
-    the fp32 oracle, with the error budget STATED here (and recorded in DESIGN.md section 2);
+    the fp32 oracle, with the error budget STATED here (and recorded in LABNOTES.md section 2);
   * config 5 (416x416, 3 classes, fp16) at its real batch of 64: size-independent properties over the whole batch and
     4 images vs the oracle;
   * `y4_pack_weights` -> fold_bn_kernel (csrc/misc_kernels.hip) with random BN mean / var / gamma against the oracle

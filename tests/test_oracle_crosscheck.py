@@ -1,4 +1,4 @@
-"""Independent cross-checks of the oracle (parity is unpinned against TensorFlow -- DESIGN.md section 2 -- so the
+"""Independent cross-checks of the oracle (parity is unpinned against TensorFlow -- LABNOTES.md section 2 -- so the
 restatement is at least checked against SECOND implementations of the same published semantics):
   * `oracle.forward.conv_block` against torch.nn modules in eval mode (Conv2d / BatchNorm2d(eps=1e-3) / Mish /
     LeakyReLU(0.1) / ZeroPad2d((1,0,1,0))): the library's own statement of Keras' Conv2D -> BatchNormalization ->

@@ -3,7 +3,7 @@
 // north_star's "LDS-staged input tiles").
 //
 // conv_igemm_kernel re-stages the activation rows of every tap: per K-tile of a 192 x 256 tile 24 KB of pixels + 32 KB of weights go
-// L2 -> LDS, and the LDS-DMA stream is what bounds its K loop (7 one-KB pieces per wave and K-tile at
+// L2 -> LDS, and the LDS-DMA stream is what bounds its K loop (LABNOTES.md section 4.1d: 7 one-KB pieces per wave and K-tile at
 // 100-185 cycles of issue each, 36 % MFMA-busy).  Here an output tile is a BAND of R full image rows of one image -- R * W <= BM
 // consecutive pixels of the NHWC tensor -- and its input for one chunk of 64 channels is the band plus one row above and below:
 // (R + 2) rows of P = roundup(W + 2, 8) LDS rows of 128 bytes (column 0 and columns > W are the conv's zero padding: out-of-range

@@ -26,7 +26,7 @@
 namespace y4 {
 
 #ifdef Y4_TRACE
-// In-kernel phase trace (kernel experiments only; scripts/trace_read.py).  Build one translation
+// In-kernel phase trace (kernel experiments only; scripts/trace_read.py, LABNOTES.md section 4.1).  Build one translation
 // unit with -DY4_TRACE=1 -DY4_TRACE_BM=<BM> -DY4_TRACE_NST=<NST> (scripts/build_variant.sh): workgroup TR_WG of the plain
 // <BM> x 256 tile with <NST> stages records s_memtime (shader clock) per wave at fixed points of K-tiles TR_KT0 .. +3, and
 // s_memrealtime (100 MHz) once per K-tile, into y4_trace_buf[k-tile][wave][point]; y4_trace_read() copies it out.

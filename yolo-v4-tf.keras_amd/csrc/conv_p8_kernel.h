@@ -1,6 +1,6 @@
 // conv_p8_kernel.h -- the reference's conv() unit (custom_layers.py:5-31) as a PHASED implicit-GEMM MFMA kernel for gfx950:
 // same GEMM view, operand roles, LDS image, K order and epilogue as conv_igemm_kernel.h (bit-identical results), another
-// schedule of the K loop.  Round 2's phase trace of the plain loop showed the two waves of a SIMD
+// schedule of the K loop.  Round 2's phase trace of the plain loop (LABNOTES.md section 4.1) showed the two waves of a SIMD
 // paying their non-MFMA instruction streams at the same time after every barrier and every load having exactly one K-tile
 // period to land.  Here
 //   * a K-tile is NP = BM/64 phases; a phase is { read-half: fragment ds_reads + LDS-DMA issue | s_barrier | MFMA-half:
@@ -70,7 +70,7 @@ template <int NP> __device__ __forceinline__ void p8_wait_phase(int ph) {      /
 // phase's pixel part -- each into the register its last user has just released, order (k-step, pixel fragment, channel
 // fragment) so that a fragment has a dozen MFMAs to land --, in the last phase of a K-tile the weight fragments of the next
 // K-tile the same way, and the LDS-DMA loads.  A wave then never issues MFMAs back to back (one wave alone gets a
-// 16x16x32 MFMA out only every ~25 cycles) and never stops multiplying to read.
+// 16x16x32 MFMA out only every ~25 cycles, LABNOTES.md section 4.0) and never stops multiplying to read.
 // Region life cycle (G = global phase index; fragments used in phase G are read during phase G-1):
 //   pixel part r of K-tile T: loaded in phase (T-2, r+1)  [r = NP-1: (T-1, 0)], retired by the wait at the end of the phase
 //   before the one that reads it, read during phase (T, r) - 1, free two phases after that read;
@@ -112,7 +112,7 @@ template <int NP> struct S9Sched {
 template <int NP, int PH> __device__ __forceinline__ void s9_wait_phase() { p8_wait_vm<S9Sched<NP>::wait(PH)>(); }
 
 // (Round 3 also built both schedules with v_mfma_f32_32x32x16: 115-117 us where the 16x16x32 forms take 96-101 -- like the
-// plain kernel's 32x32x16 tiles, DESIGN.md section 4.0 -- and removed them again.)
+// plain kernel's 32x32x16 tiles, LABNOTES.md section 4.0 -- and removed them again.)
 template <int DT, int BM, int SCHED>
 __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
     static_assert(SCHED == 8 || SCHED == 9, "8: staggered wave groups, 9: software-pipelined");

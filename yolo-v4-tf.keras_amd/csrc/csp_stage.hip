@@ -20,7 +20,7 @@
 // same 16-bit rounded inputs as its stand-alone conv_igemm kernel, and the same fp32 epilogue: outputs are
 // BIT-IDENTICAL to the unfused path (tests/test_gpu_forward.py::test_stage_fusion_is_bit_identical).
 // What bounds it: VALU, not MFMA or HBM -- Mish costs ~8 VALU ops (2 transcendental) per element and the stage has
-// 352 Mish channels per pixel.
+// 352 Mish channels per pixel (LABNOTES.md section 4.1b).
 #include "conv_chain.h"
 
 // experiment switches (scripts/build_variant.sh): CS_ABL 1 = LeakyReLU instead of Mish (VALU ablation), 2 = no output

@@ -196,7 +196,7 @@ __device__ __forceinline__ void decode_one_cell(const DecodeK& p, const DecodeCe
 // (27 % on the synthetic heads).  Only those are then read in full, one at a time.  HBM bytes per cell 1024 -> ~470.
 // Round 4: DC_SCREEN is a template parameter -- a few images (the reference's own call is ONE) are 1 421 waves of 16 cells on 1 024
 // SIMDs, each walking its ~4 flagged cells one after the other with nothing beside it to hide the loads; 4 cells per wave are four
-// times the waves with a quarter of the chain (34 -> see DESIGN.md section 4.4).  The candidate lists' order differs, NMS sorts them.
+// times the waves with a quarter of the chain (34 -> see LABNOTES.md section 4.4).  The candidate lists' order differs, NMS sorts them.
 constexpr int DC_SCREEN = 16, DC_SCREEN_SMALL = 4;
 template <int DC_SCREEN>
 __global__ __launch_bounds__(256) void decode_cell_kernel(const DecodeK p) {

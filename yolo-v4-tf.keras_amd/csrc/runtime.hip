@@ -1228,7 +1228,7 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
         int best_tile = 0;
         for (int tile = 1; tile <= ntiles; ++tile) {
             // the 32x32x16-MFMA tiles sum in another order than all the others: offering them here would make the outputs
-            // depend on the tuner's choice.  They are measured slower anyway and stay explicit-only.
+            // depend on the tuner's choice.  They are measured slower anyway (LABNOTES.md section 4.1) and stay explicit-only.
             if (tuner_skips_tile(tile)) continue;
             set_tile(oi, tile);
             const float ms = time_op(oi, images_of(oi), false);

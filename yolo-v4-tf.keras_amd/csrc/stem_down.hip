@@ -52,7 +52,7 @@ constexpr int SD_UNROLL = 4;                            // stem tiles whose gath
 // into registers one output row AHEAD -- issued before the previous row's conv phase, which hides their round trip -- and its
 // remaining tiles are requested first thing in the stem phase, so that they land while the preloaded ones are converted,
 // multiplied and stored.  Before, every wave of the workgroup started a row by waiting for its own loads (the stem phase of a
-// row was 40 % idle: in-kernel trace).  Same values through the same MFMAs: bit-identical.
+// row was 40 % idle: in-kernel trace, LABNOTES.md section 4.2a).  Same values through the same MFMAs: bit-identical.
 #define SD_PRELOAD 1
 #endif
 #ifndef SD_TAPBAR
