@@ -207,12 +207,40 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         }
     }
     int c0b = cbase + c_in;
-    int a_vo[A_IT];
-    auto set_tap = [&]() {
-        const int tap = ky * p.ksize + kx;
-        const int tap_off = ((ky * p.W + kx) * p.in_cstride) * ES;
+    // Per tap change (every K-tile of a 3x3 conv with 128-byte rows since the K order is chunk-major -- and a single wave issues one
+    // instruction per ~8 cycles, so a single image's latency-bound small tiles feel every instruction here; scripts/conv_b1_ab.py):
+    //   TAPVEC (tiles that stage at most two rows per thread): the nine tap offsets of a row are computed ONCE into a 16-element
+    //   register vector and the tap's entry is picked by a uniform index (s_set_gpr_idx: three instructions, no arithmetic);
+    //   otherwise a row's offset moves by a SCALAR step -- one column, a row wrap, or back to tap 0 -- and an invalid tap becomes the
+    //   out-of-range offset through one bit-field extract + one bit-field insert: 3 VALU per row.
+    constexpr bool TAPVEC = A_IT <= 2;
+    typedef int i32x16 __attribute__((ext_vector_type(16)));
+    const int cs = p.in_cstride * ES;
+    const int step_row = (p.W - (p.ksize - 1)) * cs, step_back = -((p.ksize - 1) * p.W + (p.ksize - 1)) * cs;
+    int tap = ky * p.ksize + kx;
+    int a_cur[A_IT], a_vo[A_IT];
+    i32x16 a_tapv[TAPVEC ? A_IT : 1];
+    if constexpr (TAPVEC) {
 #pragma unroll
-        for (int j = 0; j < A_IT; ++j) a_vo[j] = ((a_mask[j] >> tap) & 1) ? a_off[j] + tap_off : (int)0x80000000;   // >= num_records -> zeros
+        for (int j = 0; j < A_IT; ++j)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ty = p.ksize == 3 ? t / 3 : 0, tx = p.ksize == 3 ? t - ty * 3 : 0;      // (1x1: only entry 0 is ever picked)
+                a_tapv[j][t] = ((a_mask[j] >> t) & 1) ? a_off[j] + ((ty * p.W + tx) * p.in_cstride) * ES : (int)0x80000000;
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) a_cur[j] = a_off[j] + ((ky * p.W + kx) * p.in_cstride) * ES;
+    }
+    auto set_tap = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            if constexpr (TAPVEC) a_vo[j] = a_tapv[j][tap];
+            else {
+                const int dead = ~((int)((unsigned)a_mask[j] << (31 - tap)) >> 31);      // all ones when bit `tap` of the validity mask is clear
+                a_vo[j] = (dead & (int)0x80000000) | (~dead & a_cur[j]);                   // >= num_records -> zeros
+            }
+        }
     };
     set_tap();
     auto stage = [&](int buf) {
@@ -227,12 +255,24 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
             if (!B_PART || tid < BN * CPR)                                   // wave-uniform predicate
                 buffer_load16_lds(rs_wt, smem + db + j * (NT * 16), b_off[j], ktb);
         ktb += BKB;
+        // The tap advance is the COMMON case since the K order is chunk-major: marked likely so that the block stays in line.  (As
+        // scalar selects instead of branches the compiler moves the cursor into vector registers -- v_cndmask + v_readfirstlane, 300
+        // scratch accesses: 6x slower, measured.)
         c_in += BKB;
-        if (c_in >= chb) {                          // next tap of this chunk; after the last tap the next chunk
+        if (__builtin_expect(c_in >= chb, 1)) {     // next tap of this chunk; after the last tap the next chunk
             c_in = 0;
-            if (++kx >= p.ksize) {
-                kx = 0;
-                if (++ky >= p.ksize) { ky = 0; cbase += chb; }
+            int step = cs;
+            ++tap;
+            if (TAPVEC) {
+                if (__builtin_expect(tap >= p.ksize * p.ksize, 0)) { tap = 0; cbase += chb; }
+            } else {
+                if (__builtin_expect(++kx >= p.ksize, 0)) {
+                    kx = 0;
+                    step = step_row;
+                    if (++ky >= p.ksize) { ky = 0; tap = 0; step = step_back; cbase += chb; }
+                }
+#pragma unroll
+                for (int j = 0; j < A_IT; ++j) a_cur[j] += step;
             }
             set_tap();
         }
