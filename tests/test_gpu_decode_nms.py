@@ -166,3 +166,27 @@ def test_more_than_the_cap_of_disjoint_boxes():
     got, ref = _compare(eng, cfg, heads, size, ncls)
     assert got[3][0] == 100 and np.all(np.diff(got[1][0]) <= 0) and np.all(got[2][0] == 1)
     eng.close()
+
+
+def test_one_score_bin_holds_more_than_a_chunk_under_a_few_better_keys():
+    """three candidates in the top score bins and ~2 000 inside ONE 2^-9-wide bin below them (more than the 1 024 keys of
+    the first NMS chunk): the histogram pivot's suffix would be those three keys alone -- the kernel must fall through to the exact
+    radix select and still return the oracle's 100 boxes (score desc, ties by box index then class)."""
+    size, ncls, n = 608, 2, 1
+    cfg, eng = _engine(size, ncls, n)
+    g = size // 8
+    boxes = [(0, 0, 1, 1 + 9 * i, 0, 0, 8.0, 8.0, (0.0, 0.0, -1.0, -1.0)) for i in range(3)]        # three confident boxes
+    k = 0
+    for gy in range(4, g, 2):
+        for gx in range(0, g, 2):
+            if k >= 2000:
+                break
+            # sigmoid(1.0) * sigmoid(1.0 + tiny) ~ 0.534: the scores of all of these share one histogram bin (score bits >> 14)
+            boxes.append((0, 0, gy, gx, k % 3, k % 2, 1.0, 1.0 + 1e-4 * (k % 11), (0.0, 0.0, -1.5, -1.5)))
+            k += 1
+    assert k > 1100
+    heads = _heads_with(size, ncls, n, boxes)
+    got, ref = _compare(eng, cfg, heads, size, ncls)
+    assert got[3][0] == 100 and np.all(np.diff(got[1][0]) <= 0)
+    assert got[1][0, 0] > 0.99 and got[1][0, 3] < 0.6
+    eng.close()

@@ -417,9 +417,12 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsK p) {
             __syncthreads();
             for (int w = wv + 1; w < NMS_THREADS / 64; ++w) suf += hb[1024 + w];
             // the lowest bin whose suffix fits the chunk (bin 0's suffix is `remaining`: it never does)
-            if (tid > 0 && suf <= chunk_cap && suf + hb[tid - 1] > chunk_cap) sh[3] = (uint32_t)tid + 1u;
+            if (tid > 0 && suf <= chunk_cap && suf + hb[tid - 1] > chunk_cap) { sh[3] = (uint32_t)tid + 1u; sh[4] = suf; }
             __syncthreads();
-            const uint32_t pb = sh[3];
+            // (one 2^-9-wide score bin holding more than a chunk while the bins above it are nearly empty would give a first
+            //  chunk of a few keys and leave the image to the slow later passes: a suffix under half a chunk falls through to the exact
+            //  radix select below, which fills the chunk)
+            const uint32_t pb = sh[3] != 0 && 2u * sh[4] >= chunk_cap ? sh[3] : 0u;
             if (pb != 0) {
                 pivot = (unsigned long long)((pb - 1u + BASE) << 14) << 32;       // the bin's lowest key
                 have_pivot = true;
