@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--cold", type=int, default=0, help="MB copied between single timed launches (evicts the L2s; > 256 also the Infinity Cache): what a launch costs IN a step rather than in a hot loop")
     a = ap.parse_args()
     import torch
     from yolo4hip import ext
@@ -77,7 +78,19 @@ def main():
                 ref = out.clone()
             same = bool(torch.equal(out, ref))
             times = []
-            for _ in range(5):
+            if a.cold:
+                if "flush" not in globals():
+                    globals()["flush"] = (torch.empty(a.cold << 20, dtype=torch.uint8, device=dev), torch.empty(a.cold << 20, dtype=torch.uint8, device=dev))
+                for _ in range(15):
+                    flush[1].copy_(flush[0])
+                    xin = x.clone()                      # the input as the previous layer leaves it: freshly written
+                    d.in_ = xin.data_ptr()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); lib.y4_conv2d(C.byref(d), ext.stream_ptr()); e1.record(); e1.synchronize()
+                    times.append(e0.elapsed_time(e1) * 1e3)
+                d.in_ = x.data_ptr()
+            else:
+              for _ in range(5):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(a.reps):

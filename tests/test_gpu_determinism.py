@@ -67,8 +67,16 @@ def test_forward_is_deterministic_with_the_shipped_schedule_under_load(dtype):
     608 x 608 / 80 classes / batch 4, while a second HIP stream keeps the GPU busy with unrelated work: same bits every time."""
     import torch
     size, ncls, n = 608, 80, 4
+    import json
+    import os
     eng = _engine(size, ncls, n, dtype, seed=1)
     eng.set_stem_fusion(True); eng.set_chain_fusion(True); eng.set_stage_fusion(True); eng.set_res_fusion(True)
+    # the tile ids and fusion verdicts of the schedule that ships for batch 32 (a tile id fits a layer by its geometry, not by the
+    # batch): the halo tiles, the halo-headed LDS pairs, the staggered 192 x 256 schedule, the residual-block kernels
+    sched = os.path.join(os.path.dirname(os.path.abspath(__import__("yolo4hip").__file__)), "schedules", f"608_80_32_{dtype}.json")
+    saved = json.load(open(sched))
+    eng.apply_schedule(saved)
+    assert any(abs(t) % 1000 in (51, 52, 53, 54) for t in saved["tiles"]), "the shipped schedule no longer uses a halo tile: pick another"
     fl, u8 = _inputs(eng, size, n)
     side = torch.cuda.Stream(device=eng.device)
     a = torch.randn(2048, 2048, device=eng.device)

@@ -68,6 +68,7 @@ struct ConvK {
     // halo tiles (conv_halo_kernel.h): an output tile is a band of h_rows full image rows (h_bands bands per image; grid_m = N * h_bands),
     // its input a halo tile of (h_rows + 2) x h_pitch LDS rows per 64-channel chunk (h_pitch = W + 2 rounded up to 8)
     int h_rows, h_bands, h_pitch;
+    int h_xmap;                    // != 0: XCD x runs channel tile x (weights larger than an L2: conv_halo_kernel.h)
     int h_abl;                     // experiments only (HALO_ABL: timing ablations of conv_halo_kernel, wrong results when != 0)
     FastDiv h_div_pitch, h_div_bands;
 };

@@ -52,7 +52,16 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_halo_kernel(const ConvK 
         const int b = blockIdx.x, qq = nwg >> 3, rr = nwg & 7, xcd = b & 7, idx = b >> 3;
         t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
     }
-    const int tile_m = (int)fastdiv((uint32_t)t, p.div_gridn), tile_n = t - tile_m * p.grid_n;
+    int tile_m = (int)fastdiv((uint32_t)t, p.div_gridn), tile_n = t - tile_m * p.grid_n;
+    if (p.h_xmap != 0 && (nwg & 7) == 0) {
+        // Layers whose weights do not fit an XCD's 4 MB L2 (512 -> 1024: 9.4 MB): an XCD keeps ONE channel tile's weights -- the
+        // latency-critical operand, one tap of look-ahead -- and streams every image's activations, which have a whole chunk of
+        // look-ahead, instead of the other way round.  L2-cold (as in a step) 512 -> 1024 @19^2 100.2 -> 95.7 us; layers whose
+        // weights fit lose with it (256 -> 512 @38^2 98 -> 103: eight times the activation traffic), so the launcher decides.
+        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+        if (p.grid_n >= 8 && (p.grid_n & 7) == 0) { const int g8 = p.grid_n >> 3; tile_n = xcd + 8 * (idx % g8); tile_m = idx / g8; }
+        else if (p.grid_n == 4 || p.grid_n == 2 || p.grid_n == 1) { const int per = 8 / p.grid_n; tile_n = xcd % p.grid_n; tile_m = idx * per + xcd / p.grid_n; }
+    }
     const int n0 = tile_n * BN;
     const int img = (int)fastdiv((uint32_t)tile_m, p.h_div_bands), band = tile_m - img * p.h_bands;
     const int R = p.h_rows, P = p.h_pitch, W = p.W, H = p.H;

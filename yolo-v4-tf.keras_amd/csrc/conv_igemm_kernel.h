@@ -158,11 +158,16 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         const int n = (int)fastdiv((uint32_t)mm, p.div_howo), rem = mm - n * HoWo;
         const int ho = (int)fastdiv((uint32_t)rem, p.div_wo), wo = rem - ho * p.Wo;
         const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-        a_off[j] = (((n * p.H + hi0) * p.W + wi0) * p.in_cstride + p.in_coff + ((q ^ tswz(row)) * EPC)) * ES;
-        int mask = 0;
-        for (int ky = 0; ky < p.ksize; ++ky)
-            for (int kx = 0; kx < p.ksize; ++kx)
-                if ((unsigned)(hi0 + ky) < (unsigned)p.H && (unsigned)(wi0 + kx) < (unsigned)p.W) mask |= 1 << (ky * p.ksize + kx);
+        // (relative to a descriptor base moved back by one row + one pixel, `tap_bias`: never negative, so that the tap's offset --
+        //  uniform over the lanes -- can ride in the scalar offset and a valid row's vector offset never changes)
+        a_off[j] = (((n * p.H + hi0 + 1) * p.W + wi0 + 1) * p.in_cstride + p.in_coff + ((q ^ tswz(row)) * EPC)) * ES;
+        // (three row bits x three column bits: a short-K layer -- conv 8 walks nine K-tiles per tile -- feels a prologue of 9 x 2 compares)
+        int mask = 1;
+        if (p.ksize == 3) {
+            const int cols = ((unsigned)wi0 < (unsigned)p.W ? 1 : 0) | ((unsigned)(wi0 + 1) < (unsigned)p.W ? 2 : 0) | ((unsigned)(wi0 + 2) < (unsigned)p.W ? 4 : 0);
+            mask = ((unsigned)hi0 < (unsigned)p.H ? cols : 0) | ((unsigned)(hi0 + 1) < (unsigned)p.H ? cols << 3 : 0) |
+                   ((unsigned)(hi0 + 2) < (unsigned)p.H ? cols << 6 : 0);
+        }
         a_mask[j] = m < p.M ? mask : 0;        // rows past M never validate -> zeros
     }
     int b_off[B_IT];
@@ -183,7 +188,8 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         }
         b_off[j] = (ch * p.K + ((q ^ tswz(row)) * EPC)) * ES;
     }
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
+    const int tap_bias = (p.W + 1) * p.in_cstride * ES;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in - tap_bias, p.in_bytes + (unsigned)tap_bias);
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(p.wt, p.wt_bytes);
     const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);          // provably uniform -> SALU/M0 path
 
@@ -206,43 +212,37 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
             nk = kt1 - kt0;
         }
     }
-    int c0b = cbase + c_in;
-    // Per tap change (every K-tile of a 3x3 conv with 128-byte rows since the K order is chunk-major -- and a single wave issues one
-    // instruction per ~8 cycles, so a single image's latency-bound small tiles feel every instruction here; scripts/conv_b1_ab.py):
-    //   TAPVEC (tiles that stage at most two rows per thread): the nine tap offsets of a row are computed ONCE into a 16-element
-    //   register vector and the tap's entry is picked by a uniform index (s_set_gpr_idx: three instructions, no arithmetic);
-    //   otherwise a row's offset moves by a SCALAR step -- one column, a row wrap, or back to tap 0 -- and an invalid tap becomes the
-    //   out-of-range offset through one bit-field extract + one bit-field insert: 3 VALU per row.
-    constexpr bool TAPVEC = A_IT <= 2;
+    // Per tap change (every K-tile of a 3x3 conv with 128-byte rows since the K order is chunk-major; a wave issues one instruction
+    // per ~5-8 cycles, so both a single image's latency-bound small tiles and the big tiles feel every instruction here --
+    // scripts/conv_b1_ab.py, and +4 % on the whole batch-32 step with the first form of this cursor):
+    //   * the tap's offset (ky W + kx) pixels is uniform over the lanes: it rides in the SCALAR offset with the chunk's, so a row's
+    //     vector offset is either its own constant a_off or the out-of-range value -- one bit-field extract + one select per row;
+    //   * TAPVEC (deep-ring tiles that stage at most two rows per thread): even that is done once -- the nine selects of a row sit in a
+    //     16-element register vector and the tap's entry is picked by a uniform index (s_set_gpr_idx).
+    constexpr bool TAPVEC = A_IT <= 2 && SN >= 5;   // (the deep rings of a single image's latency-bound tiles; a short-K batch-32 layer on a
+                                                    //  small tile would pay the table's set-up in its prologue: convs 11-16 +9 %, measured)
     typedef int i32x16 __attribute__((ext_vector_type(16)));
     const int cs = p.in_cstride * ES;
     const int step_row = (p.W - (p.ksize - 1)) * cs, step_back = -((p.ksize - 1) * p.W + (p.ksize - 1)) * cs;
     int tap = ky * p.ksize + kx;
-    int a_cur[A_IT], a_vo[A_IT];
+    int tap_off = (ky * p.W + kx) * cs;            // scalar: this tap's byte offset from the (biased) row offset
+    int a_vo[A_IT];
     i32x16 a_tapv[TAPVEC ? A_IT : 1];
     if constexpr (TAPVEC) {
 #pragma unroll
         for (int j = 0; j < A_IT; ++j)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int ty = p.ksize == 3 ? t / 3 : 0, tx = p.ksize == 3 ? t - ty * 3 : 0;      // (1x1: only entry 0 is ever picked)
-                a_tapv[j][t] = ((a_mask[j] >> t) & 1) ? a_off[j] + ((ty * p.W + tx) * p.in_cstride) * ES : (int)0x80000000;
-            }
-    } else {
-#pragma unroll
-        for (int j = 0; j < A_IT; ++j) a_cur[j] = a_off[j] + ((ky * p.W + kx) * p.in_cstride) * ES;
+            for (int t = 0; t < 9; ++t) a_tapv[j][t] = ((a_mask[j] >> t) & 1) ? a_off[j] : (int)0x80000000;
     }
     auto set_tap = [&]() {
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) {
             if constexpr (TAPVEC) a_vo[j] = a_tapv[j][tap];
-            else {
-                const int dead = ~((int)((unsigned)a_mask[j] << (31 - tap)) >> 31);      // all ones when bit `tap` of the validity mask is clear
-                a_vo[j] = (dead & (int)0x80000000) | (~dead & a_cur[j]);                   // >= num_records -> zeros
-            }
+            else a_vo[j] = ((a_mask[j] >> tap) & 1) ? a_off[j] : (int)0x80000000;      // >= num_records -> zeros
         }
     };
     set_tap();
+    int c0b = cbase + c_in + tap_off;
     auto stage = [&](int buf) {
         const int da = buf * STAGE + wave_lds;
         const int db = da + BM * BKB;
@@ -261,22 +261,16 @@ __global__ __launch_bounds__(64 * WM * WN, CHAIN ? 2 : 1) void conv_igemm_kernel
         c_in += BKB;
         if (__builtin_expect(c_in >= chb, 1)) {     // next tap of this chunk; after the last tap the next chunk
             c_in = 0;
-            int step = cs;
             ++tap;
-            if (TAPVEC) {
-                if (__builtin_expect(tap >= p.ksize * p.ksize, 0)) { tap = 0; cbase += chb; }
-            } else {
-                if (__builtin_expect(++kx >= p.ksize, 0)) {
-                    kx = 0;
-                    step = step_row;
-                    if (++ky >= p.ksize) { ky = 0; tap = 0; step = step_back; cbase += chb; }
-                }
-#pragma unroll
-                for (int j = 0; j < A_IT; ++j) a_cur[j] += step;
+            tap_off += cs;
+            if (__builtin_expect(++kx >= p.ksize, 0)) {
+                kx = 0;
+                tap_off += step_row - cs;
+                if (++ky >= p.ksize) { ky = 0; tap = 0; tap_off = 0; cbase += chb; }
             }
             set_tap();
         }
-        c0b = cbase + c_in;
+        c0b = cbase + c_in + tap_off;
     };
 
     // ---- weight touch (conv_common.h): this channel tile's weight block, BN rows x K, is contiguous

@@ -152,11 +152,14 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
         const int n = (int)fastdiv((uint32_t)mm, p.div_howo), rem = mm - n * HoWo;
         const int ho = (int)fastdiv((uint32_t)rem, p.div_wo), wo = rem - ho * p.Wo;
         const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-        a_off[j] = (((n * p.H + hi0) * p.W + wi0) * p.in_cstride + p.in_coff + ((q ^ tswz(r0)) * EPC)) * ES;
-        int mask = 0;                              // bit ky*ksize + kx: that tap reads inside the image (else zeros)
-        for (int ky = 0; ky < p.ksize; ++ky)
-            for (int kx = 0; kx < p.ksize; ++kx)
-                if ((unsigned)(hi0 + ky) < (unsigned)p.H && (unsigned)(wi0 + kx) < (unsigned)p.W) mask |= 1 << (ky * p.ksize + kx);
+        // (relative to a descriptor base moved back by one row + one pixel -- conv_igemm_kernel.h: the tap's offset rides in the scalar offset)
+        a_off[j] = (((n * p.H + hi0 + 1) * p.W + wi0 + 1) * p.in_cstride + p.in_coff + ((q ^ tswz(r0)) * EPC)) * ES;
+        int mask = 1;                              // bit ky*ksize + kx: that tap reads inside the image (else zeros)
+        if (p.ksize == 3) {
+            const int cols = ((unsigned)wi0 < (unsigned)p.W ? 1 : 0) | ((unsigned)(wi0 + 1) < (unsigned)p.W ? 2 : 0) | ((unsigned)(wi0 + 2) < (unsigned)p.W ? 4 : 0);
+            mask = ((unsigned)hi0 < (unsigned)p.H ? cols : 0) | ((unsigned)(hi0 + 1) < (unsigned)p.H ? cols << 3 : 0) |
+                   ((unsigned)(hi0 + 2) < (unsigned)p.H ? cols << 6 : 0);
+        }
         a_mask[j] = m < p.M ? mask : 0;
     }
     int b_vo[4];
@@ -168,7 +171,8 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
         const int ch = chunk_channel(n0 + wb * WCH, jn >> 1, g) + (jn & 1) * 4 + r;
         b_vo[j] = (ch * p.K + ((q ^ tswz(row)) * EPC)) * ES;
     }
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
+    const int tap_bias = (p.W + 1) * p.in_cstride * ES;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in - tap_bias, p.in_bytes + (unsigned)tap_bias);
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(p.wt, p.wt_bytes);
     const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
     // (the touch has its own TOUCH_LDS bytes behind the two K-tiles: conv_common.h)
@@ -179,10 +183,11 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
     const int chb = k_chunk_channels(p.Cin, p.ksize) * ES;
     int tap = 0, ky = 0, kx = 0, c0b = 0, cbase = 0, c_in = 0, ktb = 0, lk = 0;
     int a_vo[NP];
+    int tap_off = 0;                               // scalar: the tap's byte offset, part of the scalar offset c0b
     auto set_tap = [&]() {
-        const int tap_off = ((ky * p.W + kx) * p.in_cstride) * ES;
+        tap_off = ((ky * p.W + kx) * p.in_cstride) * ES;
 #pragma unroll
-        for (int j = 0; j < NP; ++j) a_vo[j] = ((a_mask[j] >> tap) & 1) ? a_off[j] + tap_off : (int)0x80000000;
+        for (int j = 0; j < NP; ++j) a_vo[j] = ((a_mask[j] >> tap) & 1) ? a_off[j] : (int)0x80000000;
     };
     set_tap();
     // the cursor's K-tile -> LDS stage st: pixel part r, the four weight parts; `advance` moves the cursor to the next K-tile
@@ -207,7 +212,6 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
             }
             moved = true;
         }
-        c0b = cbase + c_in;
         if (lk >= nk) {                            // past the last K-tile: keep the load count, move no bytes
 #pragma unroll
             for (int j = 0; j < NP; ++j) a_mask[j] = 0;
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(512, 1) void conv_p8_kernel(const ConvK p) {
             tap = 0;
         }
         if (moved || lk >= nk) set_tap();
+        c0b = cbase + c_in + tap_off;
     };
     const int rowA = (wm * 32) * BKB, rowB = A_TILE + (wn * WCH) * BKB;
     const bool full = (m0 + BM <= p.M) && (n0 + 256 <= p.cout_store);

@@ -1190,7 +1190,9 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
     // layers' weights went through since), and the long serial K loop of a few-tile launch is exactly what that hurts -- back to
     // back the same launch runs on warm weights and the unsplit tile looks as good as the split one.  So every timed launch is
     // preceded by a pass of <= 64 MB of the packed weights through the L2s, outside its event pair.
-    const bool cold = h->allow_splitk && !h2;
+    // (Y4_TUNE_COLD=1: cold timing for throughput schedules too -- an experiment switch, scripts/sched_ab_headline.sh)
+    static const bool force_cold = [] { const char* e = getenv("Y4_TUNE_COLD"); return e && e[0] == '1'; }();
+    const bool cold = (h->allow_splitk && !h2) || (force_cold && !h2);
     const size_t flush_bytes = h->wts_bytes < ((size_t)64 << 20) ? h->wts_bytes : ((size_t)64 << 20);
     auto time_op = [&](int oi, int ne, bool chained) -> float {
         if (run_both(oi, ne, chained) != Y4_OK) return -1.f;
