@@ -26,6 +26,12 @@
 
 namespace y4 {
 
+#ifndef HALO_ABLATIONS
+// 1 (kernel experiments only, scripts/halo_abl.sh builds a variant library with it): the HALO_ABL environment variable then switches
+// off parts of the K loop at run time -- bit 1 the weight loads, 2 the halo-tile loads, 4 the barrier -- for TIMING; results are wrong.
+// The regular build contains none of it.
+#define HALO_ABLATIONS 0
+#endif
 constexpr int HALO_KA_MAX = 9;     // halo-tile pieces (1 KB) a wave stages per chunk, at most (one per tap)
 
 // PAIR: an LDS pair (conv_igemm_kernel.h) with this conv as head -- BN = Cout: the finished tile stays in LDS in the K loop's
@@ -153,8 +159,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_halo_kernel(const ConvK 
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
-            if (p.h_abl & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else
-            wait_vmcnt_then_barrier<0>();
+            if (HALO_ABLATIONS && (p.h_abl & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else wait_vmcnt_then_barrier<0>();
             const int st = (c + tap) & 1;           // stage parity: K-tile index c*9 + tap; 9 is odd, so the parity alternates with c as well
             const char* const sa = smem + abuf + ky * row_shift;
             const char* const sw = lds_w + st * WSTAGE;
@@ -163,8 +169,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_halo_kernel(const ConvK 
             // Also measured and not kept: reading the NEXT tap's k-step-0 pixel fragments under this tap's k-step-1 MFMAs (legal: the
             // halo tile does not change with the tap) -- no gain on the 96 x 32 wave tile, which has the registers for it (105 us
             // against 104-107), and 44-288 bytes of scratch per lane on the 96 x 64 ones, which run at 254-256 registers as they are.
-            if ((tap < 8 || more_chunks) && !(p.h_abl & 1)) { stage_w(st ^ 1, ktb); ktb += BKB; }
-            if (more_chunks && tap < my_pieces && !(p.h_abl & 2)) stage_a(tap, (c + 1) & 1, (c + 1) * BKB);
+            if ((tap < 8 || more_chunks) && !(HALO_ABLATIONS && (p.h_abl & 1))) { stage_w(st ^ 1, ktb); ktb += BKB; }
+            if (more_chunks && tap < my_pieces && !(HALO_ABLATIONS && (p.h_abl & 2))) stage_a(tap, (c + 1) & 1, (c + 1) * BKB);
             u32x4 xf[2][MREP], wf[2][NREP];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {

@@ -168,7 +168,7 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
         k.h_div_pitch = fastdiv_make((uint32_t)hp.pitch); k.h_div_bands = fastdiv_make((uint32_t)hp.bands);
         k.grid_m = d->n * hp.bands;
         k.h_xmap = wt_bytes > ((int64_t)3 << 20) ? 1 : 0;
-        { static const int abl = [] { const char* e = getenv("HALO_ABL"); return e ? atoi(e) : 0; }(); k.h_abl = abl; }
+        { static const int abl = [] { const char* e = getenv("HALO_ABL"); return e ? atoi(e) : 0; }(); k.h_abl = abl; }      // (read only by a -DHALO_ABLATIONS=1 build of the kernel)
     }
     Y4_REQUIRE((int64_t)k.grid_n * tc.bn <= cout_pad, Y4_EINVAL, "conv2d: tile %d overruns the packed weight rows", tile);
     k.div_gridn = fastdiv_make((uint32_t)k.grid_n);
