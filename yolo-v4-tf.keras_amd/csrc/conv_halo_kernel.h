@@ -85,16 +85,23 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_halo_kernel(const ConvK 
     //      physical chunk lane%8) copies logical chunk (lane%8) ^ (row & 7) of image pixel (y0 - 1 + row / P, row % P - 1).
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(p.wt, p.wt_bytes);
-    int a_vo[HALO_KA_MAX];
-#pragma unroll
-    for (int k = 0; k < HALO_KA_MAX; ++k) {
-        const int u = wave + k * NW;
-        const int r = u * 8 + (lane >> 3), q = lane & 7;
-        const int yy = (int)fastdiv((uint32_t)r, p.h_div_pitch), xx = r - yy * P;
-        const int iy = y0 - 1 + yy, ix = xx - 1;
-        const bool ok = u < APIECES && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        a_vo[k] = ok ? (((img * H + iy) * W + ix) * p.in_cstride + p.in_coff + ((q ^ (r & 7)) * EPC)) * ES : (int)0x80000000;
-    }
+    // A piece's eight LDS rows lie in ONE halo row (P % 8 == 0), so its source offset is a wave-uniform scalar (image row, first
+    // column) plus a per-lane constant (row within the piece, swizzled chunk) -- computed when the piece is issued instead of kept:
+    // nine registers per wave in a K loop that runs at 254-256 (kept, the LDS-pair variants reloaded them from scratch every tap).
+    const int lrow = lane >> 3;
+    const int lane_part = (lrow * p.in_cstride + (((lane & 7) ^ lrow) * EPC)) * ES;
+    auto piece_off = [&](int k) {
+        int wv = wave;
+        asm volatile("" : "+s"(wv));                             // (opaque: or the optimiser computes all nine in front of the loop again)
+        const int u = wv + k * NW;                               // (wave-uniform from here ...)
+        const int r8 = u << 3;
+        const int yy = (int)fastdiv((uint32_t)r8, p.h_div_pitch), xx0 = r8 - yy * P;
+        const int iy = y0 - 1 + yy;
+        const bool row_ok = u < APIECES && (unsigned)iy < (unsigned)H;
+        const int s_base = (((img * H + iy) * W + xx0 - 1) * p.in_cstride + p.in_coff) * ES;
+        const int ix = xx0 - 1 + lrow;                           // (... per lane)
+        return row_ok && (unsigned)ix < (unsigned)W ? s_base + lane_part : (int)0x80000000;
+    };
     // Weights: as conv_igemm_kernel (row permutation of the chunked accumulator layout, source-side swizzle)
     const int q = tid % CPR, r0 = tid / CPR;
     int b_off[B_IT];
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_halo_kernel(const ConvK 
     }
     const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
     auto stage_a = [&](int k, int buf, int cbyte) {      // piece k of this wave's share of the chunk at channel byte offset cbyte
-        buffer_load16_lds(rs_in, smem + buf * ABYTES + (wave + k * NW) * 1024, a_vo[k], cbyte);
+        buffer_load16_lds(rs_in, smem + buf * ABYTES + (wave + k * NW) * 1024, piece_off(k), cbyte);
     };
     auto stage_w = [&](int st, int ktb) {
 #pragma unroll
@@ -199,14 +206,18 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_halo_kernel(const ConvK 
         __syncthreads();                                   // every wave is done with the K loop's buffers
         char* const xl = smem;
         const int xrow = wm * WPX + frow, chw = wn * WCH;
+        // (the tail's staging offsets are computed HERE, from values laundered through an empty volatile asm: hoisted in front of the K
+        //  loop -- which runs at 254-256 registers -- they cost it scratch accesses)
+        int r0b = r0, qb = q;
+        asm volatile("" : "+v"(r0b), "+v"(qb));
         int b2_off[B_IT];
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
-            const int row = r0 + j * RPI;
+            const int row = r0b + j * RPI;
             const int wb = row / WCH, pr = row - wb * WCH;
             const int jn = pr >> 4, i = pr & 15, g = i >> 2, r = i & 3;
             const int ch = chunk_channel(wb * WCH, jn >> 1, g) + (jn & 1) * 4 + r;
-            b2_off[j] = (ch * p.tail_k + ((q ^ swz<CPR>(row)) * EPC)) * ES;
+            b2_off[j] = (ch * p.tail_k + ((qb ^ swz<CPR>(row)) * EPC)) * ES;
         }
         const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(p.tail[0].w, p.tail_w_bytes);
         auto stage_w2 = [&](int buf, int kt) {
@@ -223,9 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_halo_kernel(const ConvK 
 #pragma unroll
             for (int j = 0; j < NREP; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int nk2 = p.tail_k >> 6;
-        int xo2[2];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) xo2[kk] = frow * BKB + (((kk * 4 + fg) ^ swz<CPR>(frow)) * 16);
+        const int (&xo2)[2] = xo;
         for (int kt = 0; kt < nk2; ++kt) {
             wait_vmcnt_then_barrier<0>();
             if (kt + 1 < nk2) stage_w2((kt + 1) & 1, kt + 1);
