@@ -407,7 +407,8 @@ def main():
             "autotuned in this process (y4_autotune)"
         eng.predict_device(imgs, outs)                        # real activations in the workspace
         tune_pair = args.in_flight > 1 and args.pair_passes > 0     # some decisions judged with D batches in flight
-        if not tune_pair:
+        tiles = None
+        if not tune_pair and rank == 0:                           # ONE tuning run per job: rank 0's, broadcast below
             tiles = eng.autotune(hi - lo, reps=args.tune_reps)    # untimed, one-off: fastest tile / fusion per layer (bit-identical results)
     else:
         tiles = None
@@ -420,9 +421,17 @@ def main():
     from yolo4hip.engine import InFlight
     depth = max(1, args.in_flight)
     fl = InFlight(eng, depth)
-    if tune_pair:                                              # engine 0 and its sibling tuned TOGETHER on their two streams
+    if tune_pair and rank == 0:                                # engine 0 and its sibling tuned TOGETHER on their two streams
         fl.engines[1].predict_device(imgs, outs)
         tiles = fl.autotune(hi - lo, reps=args.tune_reps, passes=args.pair_passes)
+    if not args.no_autotune and not args.load_tiles and world > 1:
+        mine = {"tiles": tiles, "stage_fusion": bool(eng.stage_fusion_active()), "res_fusion_mask": int(eng.res_fusion_mask())} \
+            if rank == 0 else None
+        got = D.share_schedule(mine, src=0)                    # every rank runs rank 0's tile set
+        if rank != 0:
+            for e in fl.engines:
+                e.apply_schedule(got)
+            tiles = got["tiles"]
     if not args.no_autotune and not args.load_tiles:
         if staged:
             staged = bool(eng.stage_fusion_active())          # the tuner may have turned the stage kernel off
@@ -506,6 +515,7 @@ def main():
     my_ms = statistics.median(own) / args.steps * 1e3
     rank_ms = [float(v) for v in D.gather_objects(my_ms)]
     rank_digests = D.gather_objects(digest)                  # every rank's outputs of its last step (its own shard of the batch)
+    rank_tiles = D.gather_objects(hashlib.sha256(json.dumps(eng.get_tiles()).encode()).hexdigest()[:16])   # ... and its tile set
 
     if rank == 0:
         dt = statistics.median(blocks)
@@ -546,6 +556,7 @@ def main():
                        "sharding": f"batch split over {world} rank(s), no data-path collective"},
             "outputs_sha256": digest,
             "rank_outputs_sha256": rank_digests if world > 1 else None,
+            "rank_tiles_sha256": rank_tiles if world > 1 else None,
             "first_image": lo,
             "blocks_ms_per_step": [round(b / args.steps * 1e3, 4) for b in blocks],
             "rank_ms_per_step": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4),

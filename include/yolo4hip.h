@@ -12,7 +12,10 @@
  *     as torch-ROCm tensors).  A handle never allocates device memory: scratch comes out of the bound
  *     workspace.  (Only the standalone y4_conv2d lazily allocates one 256-byte zero page per process.)
  *   - every launch goes on the caller's `stream` (a hipStream_t passed as void*; NULL = default stream).
- *     Calls are asynchronous; the caller synchronises.
+ *     Calls are asynchronous; the caller synchronises.  All calls on ONE handle must be enqueued in stream order (on one
+ *     stream, or on streams the caller orders with events): a handle keeps host-side notes of what its workspace holds
+ *     (which head wrote the objectness side array for how many images, whether the decode counters are clean) that are
+ *     updated when a call is ENQUEUED, after its launches succeeded -- not when it completes.
  *   - activations are NHWC.  Images are float32 [n, H, W, 3] in [0,1] (what `Yolov4.preprocess_img`
  *     produces, reference models.py:95-98, after Keras' cast to float32).
  *   - one handle per process/GPU; a handle is not re-entrant.

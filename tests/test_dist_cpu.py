@@ -59,6 +59,11 @@ def _worker(rank, world, port, ret):
     lo4, hi4 = D.shard_range(world - 1, rank, world)
     g4 = D.gather_results([torch.arange(lo4, hi4, dtype=torch.int32), torch.zeros((hi4 - lo4, 100, 4))], world - 1)
     assert np.array_equal(g4[0], np.arange(world - 1, dtype=np.int32)) and g4[1].shape == (world - 1, 100, 4)
+    # 5. one schedule per job: every rank ends up with rank 0's dict (Engine.ensure_schedule(share=True), bench.py), None included
+    assert D.group_rank_world() == (rank, world)
+    sched = D.share_schedule({"tiles": list(range(110)), "stage_fusion": True, "res_fusion_mask": 5} if rank == 0 else {"tiles": [rank]})
+    assert sched == {"tiles": list(range(110)), "stage_fusion": True, "res_fusion_mask": 5}
+    assert D.share_schedule(None if rank == 0 else {"tiles": [1]}) is None
     D.barrier()
     ret[rank] = (ok_bcast, ok_gather, mx, mxs)
     torch.distributed.destroy_process_group()
@@ -73,6 +78,15 @@ def _protocol(world):
     for rank in range(world):
         ok_bcast, ok_gather, mx, mxs = ret[rank]
         assert ok_bcast and ok_gather and mx == 9.0 + world and mxs == [float(world), 5.0, 3.0]
+
+
+def test_share_schedule_is_the_identity_without_a_process_group():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "yolo-v4-tf.keras_amd"))
+    from yolo4hip import dist as D
+    assert D.group_rank_world() == (0, 1)
+    d = {"tiles": [1, 2, 3]}
+    assert D.share_schedule(d) is d and D.share_schedule(None) is None
 
 
 def test_two_rank_gloo_protocol():

@@ -22,14 +22,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_child(extra_env, size=160, classes=3, batch=4, ranks=1, extra_args=()):
+def _run_child(extra_env, size=160, classes=3, batch=4, ranks=1, extra_args=(), autotune=False):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.update(extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--blocks", "1",
-           "--warmup", "1", "--no-cpu-baseline", "--no-latency", "--no-autotune", "--size", str(size), "--classes", str(classes),
-           "--batch", str(batch)] + list(extra_args)
+           "--warmup", "1", "--no-cpu-baseline", "--no-latency", "--size", str(size), "--classes", str(classes),
+           "--batch", str(batch)] + ([] if autotune else ["--no-autotune"]) + list(extra_args)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -70,3 +70,17 @@ def test_two_ranks_with_real_engines_on_one_gpu():
     assert first["outputs_sha256"] == two["rank_outputs_sha256"][0]
     assert second["outputs_sha256"] == two["rank_outputs_sha256"][1], "rank 1 (adopted weights, its own shard) differs from one process"
     assert second["first_image"] == 4
+
+
+def test_two_ranks_run_rank_zeros_tuned_schedule():
+    """a shape nothing ships for is tuned ONCE per job -- rank 0 runs y4_autotune, the tile ids and fusion switches go
+    to the other rank by broadcast (dist.share_schedule), both ranks report the same tile set, and (16-bit schedules without
+    split-K ids being pure speed choices) the outputs equal those of the un-tuned two-rank run."""
+    share = {"Y4_SHARE_GPU": "1", "Y4_DIST_BACKEND": "gloo"}
+    tuned = _run_child(share, ranks=2, autotune=True, extra_args=["--in-flight", "1"])
+    assert tuned["n_gpus"] == 2 and len(tuned["rank_tiles_sha256"]) == 2
+    assert tuned["rank_tiles_sha256"][0] == tuned["rank_tiles_sha256"][1]
+    assert "autotuned" in tuned["schedule"]
+    plain = _run_child(share, ranks=2, extra_args=["--in-flight", "1"])
+    assert plain["rank_tiles_sha256"][0] == plain["rank_tiles_sha256"][1] != tuned["rank_tiles_sha256"][0]
+    assert plain["rank_outputs_sha256"] == tuned["rank_outputs_sha256"]

@@ -55,8 +55,14 @@ class Yolov4(object):
         assert self.num_classes > 0, 'no classes detected!'
         self._dtype, self._max_batch, self._synth_seed, self._device = dtype, max_batch, synth_seed, device
         self._device_preprocess = device_preprocess
-        # tune-on-first-use of a shape without a shipped / cached schedule: on unless YOLO4HIP_TUNE=0 (or tune=False)
+        # A shape without a shipped / cached schedule is tuned ONCE (a full-size predict + y4_autotune on `max_batch` synthetic
+        # images: seconds at 160^2, ~20 s at 608^2 x 32; written to $YOLO4HIP_CACHE, default ~/.cache/yolo4hip):
+        #   tune=None (default)  on the first predict of this object, not in the constructor; YOLO4HIP_TUNE=0: never
+        #   tune=True            now, in the constructor          tune=False   never (built-in tile heuristic)
+        # Under an initialised torch.distributed group of more than one rank the constructor is a COLLECTIVE: rank 0 resolves
+        # (and, if allowed, tunes) the schedule now and broadcasts it, so every rank runs the same tile set.
         self._tune = (os.environ.get('YOLO4HIP_TUNE', '1') != '0') if tune is None else bool(tune)
+        self._tune_eager = tune is True
         self.build_model(load_pretrained=True if self.weight_path else False)
 
     def build_model(self, load_pretrained=True):
@@ -64,9 +70,9 @@ class Yolov4(object):
         # alias_workspace: like the reference's Keras model, the facade keeps no intermediate activations (2.7x less HBM)
         self.engine = Engine(self.num_classes, self.config, max_batch=self._max_batch, dtype=self._dtype,
                              device=self._device, alias_workspace=True)
-        self.yolo_model = _KerasLikeModel(self.engine.forward_heads, 'yolo_model')
+        self.yolo_model = _KerasLikeModel(self._tuned_first(self.engine.forward_heads), 'yolo_model')
         print(f"nms iou: {self.config['iou_threshold']} score: {self.config['score_threshold']}")
-        self.inference_model = _KerasLikeModel(self.engine.predict, 'inference_model')
+        self.inference_model = _KerasLikeModel(self._tuned_first(self.engine.predict), 'inference_model')
         self.training_model = None      # training is out of scope (inference-only framework)
         if load_pretrained and self.weight_path and self.weight_path.endswith('.weights'):
             load_weights(self, self.weight_path)
@@ -75,9 +81,32 @@ class Yolov4(object):
             # the reference leaves Keras' random initialisation in place; ours is the seeded synthetic set
             self._set_weights(W.flatten(W.synth_weights(self.plan, self._synth_seed)))
         # No silent un-tuned shapes: the tuned schedule that ships for this (size, classes, batch, dtype), else the one
-        # tuned on this machine before, else tune now -- once, cached on disk -- and say which is active.  16-bit schedules without
-        # split-K ids are bit-identical scheduling choices (tests/test_gpu_forward.py); `tune=False` keeps the built-in heuristic.
-        self.schedule_source = self.engine.ensure_schedule(tune=self._tune)
+        # tuned on this machine before, else tune -- once, cached on disk -- and say which is active.  Schedules without split-K
+        # ids are bit-identical scheduling choices (tests/test_gpu_forward.py), so WHEN the tuning happens changes no result.
+        from . import dist as D
+        self._tune_pending = False
+        if D.group_rank_world()[1] > 1:
+            self.schedule_source = self.engine.ensure_schedule(tune=self._tune, share=True)
+        elif self._tune_eager or not self._tune:
+            self.schedule_source = self.engine.ensure_schedule(tune=self._tune)
+        else:
+            self.schedule_source = self.engine.ensure_schedule(tune=False, verbose=False)
+            self._tune_pending = self.schedule_source[0] == 'heuristic'
+            if self._tune_pending:
+                print('schedule: none ships or is cached for this shape -- tuned on the first predict (tune=True: in the constructor)')
+            else:
+                self.engine.say_schedule()
+
+    def _ensure_tuned(self):
+        if self._tune_pending:
+            self._tune_pending = False
+            self.schedule_source = self.engine.ensure_schedule(tune=True)
+
+    def _tuned_first(self, fn):
+        def call(x, **kw):
+            self._ensure_tuned()
+            return fn(x, **kw)
+        return call
 
     def _set_weights(self, flat):
         """flat: the Darknet-order float32 stream (weights.flatten).  Kept on the host like Keras keeps its variables,
@@ -125,9 +154,9 @@ class Yolov4(object):
                                  f"{flat.size} floats; this model has {list(self.img_size)}, {self.num_classes}, "
                                  f"{self.plan.n_params}")
         self._set_weights(flat)
-        self.yolo_model = _KerasLikeModel(self.engine.forward_heads, 'yolo_model')
+        self.yolo_model = _KerasLikeModel(self._tuned_first(self.engine.forward_heads), 'yolo_model')
         self.inference_model = _KerasLikeModel(
-            lambda x: self.engine.predict(x, iou_threshold=0.413, score_threshold=0.3), 'inference_model')
+            self._tuned_first(lambda x: self.engine.predict(x, iou_threshold=0.413, score_threshold=0.3)), 'inference_model')
 
     # ---- out of scope (training)
     def fit(self, *a, **k):
@@ -224,6 +253,7 @@ class Yolov4(object):
         img = self.preprocess_img(raw_img)
         imgs = np.expand_dims(img, axis=0)
         print(f'nms iou: {iou_threshold} score: {score_threshold}')
+        self._ensure_tuned()
         pred_output = self.engine.predict(imgs, iou_threshold=iou_threshold, score_threshold=score_threshold)
         detections = prepost.get_detection_data(img=raw_img, model_outputs=pred_output, class_names=self.class_names)
         prepost.draw_bbox(raw_img, detections, cmap=self.class_color, random_color=True)

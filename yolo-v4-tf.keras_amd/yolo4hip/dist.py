@@ -40,6 +40,25 @@ def init_process_group(backend=None):
     return rank, local_rank, world
 
 
+def group_rank_world():
+    """(rank, world size) of the initialised default process group; (0, 1) without one."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def share_schedule(saved, src=0):
+    """Every rank returns rank `src`'s schedule dict (tile ids + fusion switches: `Engine.ensure_schedule`) -- or None if `src`
+    has none.  A COLLECTIVE under a process group (host-side pickle broadcast, a few KB, init time only); the identity without."""
+    import torch.distributed as dist
+    if group_rank_world()[1] == 1:
+        return saved
+    box = [saved if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
 def shard_range(n_total, rank, world):
     """Contiguous block partition of images [0, n_total): rank r gets [lo, hi).  Remainders go to the
     lowest ranks, so shards differ by at most one image."""

@@ -477,14 +477,18 @@ class Engine:
             ext.check(self.lib.y4_get_conv_output(self.handle, conv_idx, n, ext.ptr(out), out.numel(), ext.stream_ptr()))
         return out.cpu().numpy()
 
+    def get_tiles(self):
+        """The 110 tile ids this engine runs (y4_get_tiles)."""
+        tiles = (C.c_int32 * 110)()
+        ext.check(self.lib.y4_get_tiles(self.handle, tiles, 110))
+        return list(tiles)
+
     def autotune(self, n=None, reps=3):
         """Pick the fastest tile configuration per conv layer by measurement (results are bit-identical)."""
         n = int(n or self.max_batch)
         with self.torch.cuda.device(self.device):
             ext.check(self.lib.y4_autotune(self.handle, n, int(reps), ext.stream_ptr()))
-        tiles = (C.c_int32 * 110)()
-        ext.check(self.lib.y4_get_tiles(self.handle, tiles, 110))
-        return list(tiles)
+        return self.get_tiles()
 
     def autotune_pair(self, other, stream, other_stream, n=None, reps=3, passes=15):
         """`autotune` with throughput as objective, for two batches in flight (`InFlight`): every candidate is timed on this
@@ -495,9 +499,7 @@ class Engine:
         with self.torch.cuda.device(self.device):
             ext.check(self.lib.y4_autotune_pair(self.handle, other.handle, n, int(reps), C.c_void_p(stream.cuda_stream),
                                                 C.c_void_p(other_stream.cuda_stream), int(passes)))
-        tiles = (C.c_int32 * 110)()
-        ext.check(self.lib.y4_get_tiles(self.handle, tiles, 110))
-        return list(tiles)
+        return self.get_tiles()
 
     # ---------------------------------------------------------------- shipped schedules
     def shipped_schedule(self):
@@ -531,75 +533,96 @@ class Engine:
         ver = self.lib.y4_version().decode().replace(" ", "_").replace("/", "_")
         return os.path.join(root, "schedules", f"{self.img_size}_{self.num_classes}_{self.max_batch}_{self.dtype}_{arch}_{ver}.json")
 
-    def ensure_schedule(self, tune=True, verbose=True):
+    def ensure_schedule(self, tune=True, verbose=True, share=False):
         """Make sure this engine runs a TUNED schedule, and say which: (1) the one that ships with the package for this (image side,
         classes, batch, dtype), else (2) the one a previous process tuned on this machine (`schedule_cache_path`), else (3) tune
-        now -- all fusions on, `autotune` on a synthetic batch of `max_batch` images, split-K offered only to latency-sized engines
-        (`max_batch <= LATENCY_BATCH`) that ask for it (YOLO4HIP_LATENCY=1) -- and write it to the cache.  The weights must be loaded.  Every schedule without split-K ids
-        gives the same bits; one with them is tested against the oracle instead (`"splitk": true` in the file).  Returns
-        (source, path): source in 'shipped' | 'cached' | 'tuned' | 'heuristic' (tune=False and nothing found)."""
-        import json
-        import os
-        def use(saved):
-            if self.dtype != "f32":
-                if self.img_size <= 640:
-                    self.set_stem_fusion(True)
-                self.set_chain_fusion(True)
-                self.set_stage_fusion(True)
-                self.set_res_fusion(True)
-            self.apply_schedule(saved)
-        src, path = "heuristic", None
-        saved = self.shipped_schedule()
-        if saved is not None and len(saved.get("tiles", [])) == 110:
-            use(saved)
-            src, path = "shipped", saved["path"]
-        else:
-            path = self.schedule_cache_path()
-            try:
-                saved = json.load(open(path))
-                if len(saved.get("tiles", [])) != 110:
-                    raise ValueError("stale")
-                use(saved)
-                src = "cached"
-            except (OSError, ValueError, ext.Y4Error):
-                saved = None
-            if saved is None and tune:
-                torch = self.torch
-                if self.dtype != "f32":
-                    if self.img_size <= 640:
-                        self.set_stem_fusion(True)
-                    self.set_chain_fusion(True)
-                    self.set_stage_fusion(True)
-                    self.set_res_fusion(True)
-                # split-K ids only on request (ADVICE r4): which of them win is decided by this machine's timing, and they change
-                # the fp32 summation order -- a schedule tuned on first use would make low-order bits machine-dependent.  The
-                # shipped batch-1 schedules have them (one fixed file, tested against the oracle); YOLO4HIP_LATENCY=1 opts in here.
-                splitk = self.max_batch <= self.LATENCY_BATCH and os.environ.get("YOLO4HIP_LATENCY", "0") == "1"
-                self.set_splitk(splitk)
-                from . import weights as W
-                imgs = torch.from_numpy(W.synth_images(self.max_batch, self.img_size, seed=0)).to(self.device)
-                self.predict_device(imgs)                      # real activations in the workspace
-                tiles = self.autotune(self.max_batch, reps=3)
-                self.set_splitk(False)
-                saved = {"size": self.img_size, "classes": self.num_classes, "batch": self.max_batch, "dtype": self.dtype,
-                         "tiles": tiles, "stage_fusion": bool(self.stage_fusion_active()) if self.dtype != "f32" else False,
-                         "res_fusion_mask": int(self.res_fusion_mask()) if self.dtype != "f32" else 0, "in_flight": 1,
-                         "splitk": any(abs(t) % 1000 >= 100 or abs(t) // 1000 >= 100 for t in tiles),
-                         "tuned_on": torch.cuda.get_device_properties(self.device).gcnArchName}
-                try:
-                    os.makedirs(os.path.dirname(path), exist_ok=True)
-                    tmp = path + f".{os.getpid()}.tmp"
-                    json.dump(saved, open(tmp, "w"))
-                    os.replace(tmp, path)
-                except OSError:
-                    path = None                                # read-only home: tuned for this process only
-                src = "tuned"
+        now -- all fusions on, `autotune` on a synthetic batch of `max_batch` images (a full-size predict + a few launches per
+        candidate tile: seconds at 160^2, about 20 s at 608^2 x 32), split-K offered only to latency-sized engines
+        (`max_batch <= LATENCY_BATCH`) that ask for it (YOLO4HIP_LATENCY=1) -- and write it to the cache.  The weights must be
+        loaded.  Every schedule without split-K ids gives the same bits; one with them is tested against the oracle instead
+        (`"splitk": true` in the file).  `share=True` under an initialised torch.distributed group makes the call a COLLECTIVE:
+        rank 0 resolves (1)-(3), the others take rank 0's schedule from a broadcast (source 'shared') -- one tuning run per job,
+        the same tile set on every rank.  The tuned schedule is judged one batch at a time (`"in_flight": 1`) even
+        when `predict_stream` later keeps two in flight; `bench.py --pair-passes` / `y4_autotune_pair` is the pair-judged variant.
+        Returns (source, path): source in 'shipped' | 'cached' | 'tuned' | 'shared' | 'heuristic' (tune=False and nothing found)."""
+        from . import dist as D
+        rank, world = D.group_rank_world() if share else (0, 1)
+        src, path, saved = "heuristic", None, None
+        if rank == 0:
+            src, path, saved = self._resolve_schedule(tune)
+        if world > 1:
+            saved = D.share_schedule(saved, src=0)
+            if rank != 0 and saved is not None:
+                self._use_schedule(saved)
+                src, path = "shared", None
         self.schedule_source = (src, path)
         if verbose:
-            what = {"shipped": "shipped with the package", "cached": "tuned earlier on this machine", "tuned": "tuned now (first use of this shape)",
-                    "heuristic": "NONE: built-in tile heuristic, fusion kernels off"}[src]
-            print(f"schedule: {what}" + (f" [{os.path.basename(path)}]" if path else ""))
+            self.say_schedule()
         return src, path
+
+    def say_schedule(self):
+        import os
+        src, path = self.schedule_source
+        what = {"shipped": "shipped with the package", "cached": "tuned earlier on this machine", "tuned": "tuned now (first use of this shape)",
+                "shared": "rank 0's, received by broadcast", "heuristic": "NONE: built-in tile heuristic, fusion kernels off"}[src]
+        print(f"schedule: {what}" + (f" [{os.path.basename(path)}]" if path else ""))
+
+    def _all_fusions_on(self):
+        if self.dtype != "f32":
+            if self.img_size <= 640:
+                self.set_stem_fusion(True)
+            self.set_chain_fusion(True)
+            self.set_stage_fusion(True)
+            self.set_res_fusion(True)
+
+    def _use_schedule(self, saved):
+        self._all_fusions_on()
+        self.apply_schedule(saved)
+
+    def _resolve_schedule(self, tune):
+        """(source, path, schedule dict or None) of `ensure_schedule`'s steps (1)-(3) on THIS rank; the schedule is applied."""
+        import json
+        import os
+        saved = self.shipped_schedule()
+        if saved is not None and len(saved.get("tiles", [])) == 110:
+            self._use_schedule(saved)
+            return "shipped", saved["path"], saved
+        path = self.schedule_cache_path()
+        try:
+            saved = json.load(open(path))
+            if len(saved.get("tiles", [])) != 110:
+                raise ValueError("stale")
+            self._use_schedule(saved)
+            return "cached", path, saved
+        except (OSError, ValueError, ext.Y4Error):
+            pass
+        if not tune:
+            return "heuristic", None, None
+        torch = self.torch
+        self._all_fusions_on()
+        # split-K ids only on request (ADVICE r4): which of them win is decided by this machine's timing, and they change
+        # the fp32 summation order -- a schedule tuned on first use would make low-order bits machine-dependent.  The
+        # shipped batch-1 schedules have them (one fixed file, tested against the oracle); YOLO4HIP_LATENCY=1 opts in here.
+        splitk = self.max_batch <= self.LATENCY_BATCH and os.environ.get("YOLO4HIP_LATENCY", "0") == "1"
+        self.set_splitk(splitk)
+        from . import weights as W
+        imgs = torch.from_numpy(W.synth_images(self.max_batch, self.img_size, seed=0)).to(self.device)
+        self.predict_device(imgs)                      # real activations in the workspace
+        tiles = self.autotune(self.max_batch, reps=3)
+        self.set_splitk(False)
+        saved = {"size": self.img_size, "classes": self.num_classes, "batch": self.max_batch, "dtype": self.dtype,
+                 "tiles": tiles, "stage_fusion": bool(self.stage_fusion_active()) if self.dtype != "f32" else False,
+                 "res_fusion_mask": int(self.res_fusion_mask()) if self.dtype != "f32" else 0, "in_flight": 1,
+                 "splitk": any(abs(t) % 1000 >= 100 or abs(t) // 1000 >= 100 for t in tiles),
+                 "tuned_on": torch.cuda.get_device_properties(self.device).gcnArchName}
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            tmp = path + f".{os.getpid()}.tmp"
+            json.dump(saved, open(tmp, "w"))
+            os.replace(tmp, path)
+        except OSError:
+            path = None                                # read-only home: tuned for this process only
+        return "tuned", path, saved
 
     def apply_schedule(self, saved):
         """Tiles / stage kernel / residual-block mask from a schedule dict (`shipped_schedule`, `bench.py --save-tiles`).  The
