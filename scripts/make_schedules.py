@@ -21,7 +21,8 @@ from yolo4hip.engine import Engine
 from yolo4hip.plan import build_plan
 
 out = sys.argv[1]
-shapes = sys.argv[2:] or ["416_80_32_bf16", "416_80_1_bf16", "608_80_1_bf16", "608_80_1_f32", "416_80_1_f32"]
+shapes = sys.argv[2:] or ["416_80_32_bf16", "416_80_1_bf16", "608_80_1_bf16", "608_80_1_f32", "416_80_1_f32", "416_80_32_f32",
+                         "608_80_32_f32"]      # ..._32_f32: the facade's own defaults (Yolov4(): f32, max_batch 32)
 os.makedirs(out, exist_ok=True)
 os.environ["YOLO4HIP_CACHE"] = tempfile.mkdtemp(prefix="y4sched_")
 os.environ.setdefault("YOLO4HIP_LATENCY", "1")      # the batch-1 schedules that ship carry split-K ids (tested against the oracle)

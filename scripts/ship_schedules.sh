@@ -19,5 +19,5 @@ vote() {   # name, bench args...
 vote 608_80_32_bf16 --dtype bf16
 vote 608_80_32_f16 --dtype f16
 vote 416_3_64_f16 --size 416 --classes 3 --batch 64 --dtype f16
-Y4_RETUNE=1 python scripts/make_schedules.py $out 416_80_32_bf16 416_80_1_bf16 608_80_1_bf16 608_80_1_f32 416_80_1_f32 2>&1 | tail -8
+Y4_RETUNE=1 python scripts/make_schedules.py $out 416_80_32_bf16 416_80_1_bf16 608_80_1_bf16 608_80_1_f32 416_80_1_f32 416_80_32_f32 608_80_32_f32 2>&1 | tail -8
 ls $out/*.json | grep -v run | head -20
