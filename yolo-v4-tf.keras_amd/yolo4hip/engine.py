@@ -327,6 +327,8 @@ class Engine:
 
     def _chunks(self, imgs):
         t = self._to_device_images(imgs)
+        if t.shape[0] == 0:                                 # Keras' Model.predict raises ValueError on an empty input as well
+            raise ValueError("predict: no images (input of shape %s)" % (tuple(t.shape),))
         for i in range(0, t.shape[0], self.max_batch):     # Keras predict() chunks too (batch_size=32), invisibly
             yield t[i:i + self.max_batch]
 
