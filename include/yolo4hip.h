@@ -262,6 +262,9 @@ typedef struct y4_conv_desc {
      * 2^e x tiles x BM x BN floats of partial sums.  NULL / 0 when no split tile is used. */
     void* splitk_ws;
     size_t splitk_ws_bytes;
+    /* halo2 tiles (schedule code 21: one wave per SIMD, v_mfma_32x32x16, weights read into registers): the same weights once more in
+     * MFMA-fragment order, made from `wt` by y4_pack_conv_frag32.  NULL for every other tile. */
+    const void* wt_frag;
 } y4_conv_desc;
 
 /* cout_pad (rows of the packed matrix) and bytes needed for a packed kernel */
@@ -270,6 +273,11 @@ int y4_packed_conv_bytes(int dtype, int cout, int cin, int ksize, int32_t* cout_
  * K order every conv kernel sums in); rows >= cout are zero */
 int y4_pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw_dev, void* packed_dev,
                          void* stream);
+/* 3x3 conv weights packed by y4_pack_conv_weights (16-bit dtypes, cin % 64 == 0) -> the layout the halo2 tiles read:
+ * [cout_pad / 32 channel blocks][cin / 64 chunks][9 taps][4 k-steps of 16 channels][64 lanes][8 elements], lane l of a k-step = row
+ * (l & 31) of the block in the accumulator layout's channel order, input channels 16 s + 8 (l >> 5) .. +7 of the chunk: one k-step's
+ * v_mfma_f32_32x32x16 A operand of a block is 1 KB contiguous.  Same size as the packed matrix (y4_packed_conv_bytes). */
+int y4_pack_conv_frag32(int dtype, int cout, int cin, const void* packed_dev, void* frag_dev, void* stream);
 /* One conv() unit of the reference (custom_layers.py:5-31) + optional Add (custom_layers.py:44) +
  * optional UpSampling2D (custom_layers.py:147,159) + concat-slice store (custom_layers.py:68,...). */
 int y4_conv2d(const y4_conv_desc* d, void* stream);
@@ -284,6 +292,11 @@ int y4_conv_tile_desc(int tile, int32_t cfg[6]);
  * split order and runs the epilogue).  A split launch sums in another fp32 order than the unsplit one, so with this switch the
  * tuned schedule is part of the numerical result (like the 32x32x16 tiles; tested against the oracle); off by default. */
 int y4_set_splitk(y4_handle h, int on);
+/* The halo2 tiles (schedule code 21, conv_halo2_kernel.h: the 3x3 stride-1 convs of custom_layers.py:14-24 as a one-wave-per-SIMD kernel on
+ * v_mfma_f32_32x32x16 with the weights read into registers in MFMA-fragment order) sum the K axis in k-steps of 16 instead of 32:
+ * another fixed fp32 order than the 16x16x32 tiles.  `on` lets y4_autotune offer them too; the tuned schedule then is part of the
+ * numerical result, exactly as with y4_set_splitk (tested against the oracle and for run-to-run determinism); off by default. */
+int y4_set_halo2(y4_handle h, int on);
 /* Stem conv (cin = 3, reference custom_layers.py:101): float32 images -> dtype.  `wk_dev` is an 8192-byte table
  * made by y4_pack_stem_weights from Darknet (cout,3,3,3) order: float32 [(ky*3+kx)*3+ci][cout] for the fp32
  * kernel, then (byte 4096 / 6144) the bf16 / fp16 MFMA weight fragments used by the 16-bit kernels. */

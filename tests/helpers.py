@@ -68,6 +68,14 @@ def run_conv_gpu(x, cw, k, stride, act, dtype, residual=None, upsample=False, ou
     d.out_cstride, d.out_coff = out_cs, out_pad[0]
     d.in_ = xin.data_ptr(); d.wt = packed.data_ptr(); d.scale = sc.data_ptr(); d.shift = sh.data_ptr()
     d.out = out.data_ptr(); d.tile = tile
+    frag = None
+    if k == 3 and dtype != "f32" and cin % 64 == 0 and 1 <= tile % 100 <= lib.y4_conv_tile_count():
+        cfg = (C.c_int32 * 6)()
+        ext.check(lib.y4_conv_tile_desc(tile % 100, cfg))
+        if cfg[5] == 21:                 # a halo2 tile: the weights once more in MFMA-fragment order
+            frag = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+            ext.check(lib.y4_pack_conv_frag32(did, cout, cin, ext.ptr(packed), ext.ptr(frag), ext.stream_ptr()))
+            d.wt_frag = frag.data_ptr()
     res_t = None
     if residual is not None:
         res_t = torch.from_numpy(residual).to(dev).to(td).contiguous()

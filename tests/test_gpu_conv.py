@@ -71,7 +71,7 @@ def test_conv_vs_oracle(case, dtype):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_all_tiles_agree(dtype):
-    """Every tile configuration that fits the shape gives the same result (same K order -> bitwise)."""
+    """Every tile configuration that fits the shape gives the same result (same K order -> bitwise), per MFMA shape."""
     from yolo4hip import ext
     from yolo4hip.weights import ConvWeights
     rng = np.random.default_rng(5)
@@ -92,7 +92,11 @@ def test_all_tiles_agree(dtype):
         except ext.Y4Error as e:
             assert e.code == -22      # tile does not fit this cin/cout / dtype: refused loudly, not computed wrongly
             continue
-        if cfg[5] == 32:              # 32x32x16 MFMA: another fp32 summation order; these agree among themselves
+        if cfg[5] == 21 and cfg[4] == 64:      # halo2 tiles that walk 32-channel half chunks: a third order, held to the tolerance only
+            err = np.abs(got - base)
+            assert np.all(err <= 2 * atol + 2 * rtol * np.abs(base)), f"halo2 tile {tile}: {err.max():.3e} off the 16x16 tiles"
+            continue
+        if cfg[5] == 32 or cfg[5] == 21:       # 32x32x16 MFMA (implicit GEMM, and the halo2 tiles over whole chunks): another fp32 summation order; these agree among themselves
             if base32 is None: base32 = got
             assert np.array_equal(got, base32), f"32x32 tile {tile} differs from the first one: {np.abs(got - base32).max()}"
             err = np.abs(got - base)
@@ -155,6 +159,91 @@ def test_halo_tiles_vs_oracle_and_bit_identical(case, dtype):
         if out_pad[1]:
             assert np.all(full[..., out_pad[0] + cout:] == -5.0)
     assert ran >= 1, "no halo tile fits this case"
+
+
+HALO2_CASES = HALO_CASES + [
+    (38, 256, 512, 2, "mish", False, (0, 0), (0, 0)),         # the plan's 3x3 256 -> 512 @38^2: four chunks, four channel tiles
+    (19, 512, 512, 3, "mish", True, (0, 0), (0, 0)),          # eight chunks, residual Add, 19 x 21 / 19 x 23 halo rows
+    (20, 128, 128, 3, "linear", False, (0, 0), (0, 0)),       # even width that is no stage of the plan; the general epilogue
+    (52, 128, 256, 1, "leaky", False, (64, 64), (128, 0)),    # 416 / 8; channel slices on both sides
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("case", HALO2_CASES, ids=lambda c: f"h{c[0]}_{c[1]}to{c[2]}_n{c[3]}")
+def test_halo2_tiles_vs_oracle(case, dtype):
+    """conv_halo2_kernel (tile ids with schedule code 21: one wave per SIMD, v_mfma_f32_32x32x16, halo tile in LDS, weights read into
+    registers in MFMA-fragment order) against the oracle's conv_block (reference custom_layers.py:5-31, :44) at the tolerance of every
+    other tile.  These tiles sum the K axis in k-steps of 16: the tiles that walk whole 64-channel chunks do so in the order of the
+    implicit-GEMM kernel's 32x32x16 tiles and equal those bit for bit; the ones that walk half chunks (128-byte K rows in the tile
+    table = KC 64, 64-byte = KC 32) are their own order.  Every tile must give the same bits twice."""
+    import ctypes as C
+    from yolo4hip import ext
+    from yolo4hip.weights import ConvWeights
+    side, cin, cout, n, act, use_res, in_pad, out_pad = case
+    rng = np.random.default_rng(2000 + side + cin)
+    x = quantize(rng.standard_normal((n, side, side, cin)).astype(np.float32), dtype)
+    cw = make_conv_weights(rng, cout, cin, 3)
+    cwq = ConvWeights(w=quantize(cw.w, dtype), bn=cw.bn, bias=cw.bias)
+    res = quantize(rng.standard_normal((n, side, side, cout)).astype(np.float32), dtype) if use_res else None
+    want = _ref(x, cwq, 3, 1, act, res, False)
+    atol, rtol = TOL[dtype]
+    lib = ext.load()
+    base32 = None
+    for t32 in (36, 33):                 # a 32x32x16 implicit-GEMM tile that fits the layer: the order the KC = 64 halo2 tiles share
+        try:
+            base32, _ = run_conv_gpu(x, cwq, 3, 1, act, dtype, residual=res, in_pad=in_pad, out_pad=out_pad, tile=t32)
+            break
+        except ext.Y4Error:
+            continue
+    ran = 0
+    for tile in range(1, lib.y4_conv_tile_count() + 1):
+        cfg = (C.c_int32 * 6)()
+        ext.check(lib.y4_conv_tile_desc(tile, cfg))
+        if cfg[5] != 21:
+            continue
+        try:
+            got, full = run_conv_gpu(x, cwq, 3, 1, act, dtype, residual=res, in_pad=in_pad, out_pad=out_pad, tile=tile)
+        except ext.Y4Error as e:
+            assert e.code == -22          # this band geometry / channel tile does not fit the layer: refused, not computed wrongly
+            continue
+        ran += 1
+        err = np.abs(got - want)
+        assert np.all(err <= atol + rtol * np.abs(want)), f"halo2 tile {tile}: max err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+        if cfg[4] == 128 and base32 is not None:
+            assert np.array_equal(got, base32), f"halo2 tile {tile} differs from the 32x32x16 implicit-GEMM tile: {np.abs(got - base32).max():.3e}"
+        again, _ = run_conv_gpu(x, cwq, 3, 1, act, dtype, residual=res, in_pad=in_pad, out_pad=out_pad, tile=tile)
+        assert np.array_equal(got, again), f"halo2 tile {tile} is not repeatable"
+        if out_pad[0]:
+            assert np.all(full[..., :out_pad[0]] == -5.0)
+        if out_pad[1]:
+            assert np.all(full[..., out_pad[0] + cout:] == -5.0)
+    assert ran >= 2, "fewer than two halo2 tiles fit this case"
+
+
+def test_halo2_tiles_refuse_what_they_cannot_run():
+    """A halo2 tile id on a 1x1 conv, a stride-2 conv, float32, Cin % 64 != 0 -- or without the fragment-ordered weights -- is refused
+    (Y4_EINVAL), never mis-run."""
+    import ctypes as C
+    from yolo4hip import ext
+    rng = np.random.default_rng(0)
+    for k, stride, side, cin, cout, dtype in ((1, 1, 19, 128, 128, "bf16"), (3, 2, 38, 128, 128, "bf16"), (3, 1, 19, 128, 128, "f32"),
+                                              (3, 1, 19, 32, 128, "bf16")):
+        x = quantize(rng.standard_normal((1, side, side, cin)).astype(np.float32), dtype)
+        cw = make_conv_weights(rng, cout, cin, k)
+        with pytest.raises(ext.Y4Error) as e:
+            run_conv_gpu(x, cw, k, stride, "mish", dtype, tile=55)
+        assert e.value.code == -22
+    import torch
+    lib = ext.load()
+    d = ext.y4_conv_desc()
+    buf = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda:0")
+    d.dtype = ext.DTYPE_IDS["bf16"]; d.n, d.h, d.w, d.cin = 1, 19, 19, 128
+    d.cout, d.ksize, d.stride, d.act = 128, 3, 1, 2
+    d.in_cstride, d.out_cstride = 128, 128
+    d.in_ = d.wt = d.scale = d.shift = d.out = buf.data_ptr(); d.tile = 55          # wt_frag stays NULL
+    assert lib.y4_conv2d(C.byref(d), ext.stream_ptr()) == -22
+    assert b"fragment-ordered" in lib.y4_last_error()
 
 
 def test_halo_tiles_refuse_what_they_cannot_run():

@@ -30,7 +30,7 @@ def test_struct_layouts_match_header_sizes():
     from yolo4hip import ext
     assert C.sizeof(ext.y4_config) == 4 * 4 + 18 * 4 + 3 * 4 + 3 * 4 + 2 * 4 + 2 * 4
     assert C.sizeof(ext.y4_layer_desc) == 9 * 4 + 4 + 8
-    assert C.sizeof(ext.y4_conv_desc) == 17 * 4 + 4 + 6 * 8 + 8 + 8 + 3 * 4 + 4 + 8 + 8   # ... tile+pad, out2, 3 ints, pad, split-K ws
+    assert C.sizeof(ext.y4_conv_desc) == 17 * 4 + 4 + 6 * 8 + 8 + 8 + 3 * 4 + 4 + 8 + 8 + 8   # ... tile+pad, out2, 3 ints, pad, split-K ws, wt_frag
 
 
 def test_error_reporting_host_only():

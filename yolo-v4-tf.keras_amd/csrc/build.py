@@ -20,7 +20,7 @@ OUT = os.path.join(HERE, "..", "yolo4hip", "libyolo4hip.so")
 BUILD = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 # biggest translation units first so that the parallel build ends as early as possible
-UNITS = ["conv_igemm_bf16", "conv_igemm_f16", "conv_p8_bf16", "conv_p8_f16", "conv_halo_bf16", "conv_halo_f16", "conv_igemm_bf16_fused", "conv_igemm_f16_fused", "conv_igemm_f32",
+UNITS = ["conv_igemm_bf16", "conv_igemm_f16", "conv_p8_bf16", "conv_p8_f16", "conv_halo_bf16", "conv_halo_f16", "conv_halo2_bf16", "conv_halo2_f16", "conv_igemm_bf16_fused", "conv_igemm_f16_fused", "conv_igemm_f32",
          "resblock", "csp_stage", "stem_down", "misc_kernels", "decode_nms", "runtime", "conv_igemm"]
 
 

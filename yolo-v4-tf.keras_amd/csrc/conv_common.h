@@ -71,6 +71,9 @@ struct ConvK {
     int h_xmap;                    // != 0: XCD x runs channel tile x (weights larger than an L2: conv_halo_kernel.h)
     int h_abl;                     // experiments only (HALO_ABL: timing ablations of conv_halo_kernel, wrong results when != 0)
     FastDiv h_div_pitch, h_div_bands;
+    // halo2 tiles (conv_halo2_kernel.h): the weights once more in MFMA-fragment order (pack_conv_frag32)
+    const char* wfrag;
+    unsigned wfrag_bytes;
 };
 
 template <int CPR> __device__ __forceinline__ int swz(int row) {
@@ -453,17 +456,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MREP]
 
 // A tile whose channel block is full but whose pixel rows end at m_limit (halo tiles): the fast epilogue with dropped rows where it
 // applies (16-byte stores of the compute dtype, Mish / LeakyReLU), else the general one.  Same arithmetic either way.
-template <int DT, int MREP, int NREP>
-__device__ __forceinline__ void conv_epilogue_rows(const ConvK& p, f32x4 (&acc)[MREP][NREP], int mrow, int m_limit, int chw, int fg, bool ch_full) {
+// GW = 4: 16 x 16 fragments (lane group = lane >> 4); GW = 2: the 32 x 32 blocks of conv_halo2_kernel.h (lane half = lane >> 5).
+template <int DT, int MREP, int NREP, int GW>
+__device__ __forceinline__ void conv_epilogue_rows_g(const ConvK& p, f32x4 (&acc)[MREP][NREP], int mrow, int m_limit, int chw, int fg, bool ch_full) {
     float sc[NREP * 4], sh[NREP * 4];
-    conv_epilogue_tables<NREP, 4>(p, chw, fg, sc, sh);
+    conv_epilogue_tables<NREP, GW>(p, chw, fg, sc, sh);
     if (Y4_FAST_EPI && ch_full && p.fast_epi && p.act != Y4_ACT_LINEAR && (p.act == Y4_ACT_MISH || !p.res)) {
-        if (p.act == Y4_ACT_LEAKY) conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_LEAKY, false, 4, false, true>(p, acc, sc, sh, mrow, chw, fg, nullptr, 0, 0, m_limit);
-        else if (p.res) conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_MISH, true, 4, false, true>(p, acc, sc, sh, mrow, chw, fg, nullptr, 0, 0, m_limit);
-        else conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_MISH, false, 4, false, true>(p, acc, sc, sh, mrow, chw, fg, nullptr, 0, 0, m_limit);
+        if (p.act == Y4_ACT_LEAKY) conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_LEAKY, false, GW, false, true>(p, acc, sc, sh, mrow, chw, fg, nullptr, 0, 0, m_limit);
+        else if (p.res) conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_MISH, true, GW, false, true>(p, acc, sc, sh, mrow, chw, fg, nullptr, 0, 0, m_limit);
+        else conv_epilogue_fast<DT, MREP, NREP, Y4_ACT_MISH, false, GW, false, true>(p, acc, sc, sh, mrow, chw, fg, nullptr, 0, 0, m_limit);
         return;
     }
-    conv_epilogue_with<DT, MREP, NREP>(p, acc, sc, sh, mrow, m_limit, chw, fg, false);
+    conv_epilogue_with<DT, MREP, NREP, false, GW>(p, acc, sc, sh, mrow, m_limit, chw, fg, false);
+}
+template <int DT, int MREP, int NREP>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvK& p, f32x4 (&acc)[MREP][NREP], int mrow, int m_limit, int chw, int fg, bool ch_full) {
+    conv_epilogue_rows_g<DT, MREP, NREP, 4>(p, acc, mrow, m_limit, chw, fg, ch_full);
 }
 
 // LDS pair: the head conv's tile, kept in LDS by the XL epilogue, goes to its HBM view(s) (lane re-reads the chunks it

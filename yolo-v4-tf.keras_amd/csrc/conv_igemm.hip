@@ -29,6 +29,15 @@ int conv_halo_launch(int dtype, int bm, int bn, const ConvK& k, hipStream_t s) {
     return Y4_EINVAL;
 }
 
+int conv_halo2_launch_bf16(int tile, const ConvK& k, hipStream_t s);
+int conv_halo2_launch_f16(int tile, const ConvK& k, hipStream_t s);
+int conv_halo2_launch(int dtype, int tile, const ConvK& k, hipStream_t s) {
+    if (dtype == Y4_BF16) return conv_halo2_launch_bf16(tile, k, s);
+    if (dtype == Y4_F16) return conv_halo2_launch_f16(tile, k, s);
+    set_error("conv2d: halo2 tiles are 16-bit only");
+    return Y4_EINVAL;
+}
+
 int conv_tile_count() { return kNumTiles; }
 
 // the weight touch of conv_common.h is on unless Y4_NO_WEIGHT_TOUCH=1 (A/B measurements only: results are the same)
@@ -170,6 +179,21 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
         k.h_xmap = wt_bytes > ((int64_t)3 << 20) ? 1 : 0;
         { static const int abl = [] { const char* e = getenv("HALO_ABL"); return e ? atoi(e) : 0; }(); k.h_abl = abl; }      // (read only by a -DHALO_ABLATIONS=1 build of the kernel)
     }
+    if (tc.nst == 21) {
+        // halo2 tiles (conv_halo2_kernel.h): plain launches of 3x3 stride-1 convs, 16-byte stores, weights also in fragment order
+        HaloPlan hp{};
+        Y4_REQUIRE(d->dtype != Y4_F32 && d->ksize == 3 && d->stride == 1 && d->cin % 64 == 0 && k.ntail == 0 && !pair && !split_e && !d->upsample &&
+                       !d->out_f32 && !d->out2 && halo2_plan(tile, d->h, d->w, &hp),
+                   Y4_EINVAL, "conv2d: tile %d (halo2, %d x %d) does not fit this conv (3x3 stride 1, 16-bit, cin %% 64 == 0, %d x %d map)", tile,
+                   tc.bm, tc.bn, d->h, d->w);
+        Y4_REQUIRE(d->wt_frag, Y4_EINVAL, "conv2d: tile %d (halo2) needs the fragment-ordered weights (y4_conv_desc.wt_frag, y4_pack_conv_frag32)", tile);
+        k.wfrag = (const char*)d->wt_frag; k.wfrag_bytes = (unsigned)wt_bytes;
+        k.h_rows = hp.rows; k.h_bands = hp.bands; k.h_pitch = hp.pitch;
+        k.h_div_pitch = fastdiv_make((uint32_t)hp.pitch); k.h_div_bands = fastdiv_make((uint32_t)hp.bands);
+        k.grid_m = d->n * hp.bands;
+        k.h_xmap = wt_bytes > ((int64_t)3 << 20) ? 1 : 0;
+        { static const int abl = [] { const char* e = getenv("HALO_ABL"); return e ? atoi(e) : 0; }(); k.h_abl = abl; }      // (read only by a -DHALO2_ABLATIONS=1 build)
+    }
     Y4_REQUIRE((int64_t)k.grid_n * tc.bn <= cout_pad, Y4_EINVAL, "conv2d: tile %d overruns the packed weight rows", tile);
     k.div_gridn = fastdiv_make((uint32_t)k.grid_n);
     if (split_e) {
@@ -191,6 +215,7 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
                             d->out2_cstride % epc == 0 && d->out2_coff % epc == 0),
                Y4_EINVAL, "conv2d: bad split-output description");
     const bool fused = k.pair || k.ntail > 0;
+    if (tc.nst == 21) return conv_halo2_launch(d->dtype, tile, k, stream);
     switch (d->dtype) {
         case Y4_F32:
             Y4_REQUIRE(!fused, Y4_EINVAL, "conv2d: chains and LDS pairs are 16-bit only");
@@ -249,6 +274,37 @@ __global__ void pack_tail_kernel(const float* __restrict__ w, typename Elem<DT>:
         const int ch2 = ((j2 >> 1) * 4 + (i >> 2)) * 8 + (j2 & 1) * 4 + (i & 3);
         out[idx] = Elem<DT>::st(w[ch2 * cin + 32 * s + 8 * g + e]);
     }
+}
+
+// packed 3x3 weights [cout_pad][cin/64][9][64] -> MFMA-fragment order of the halo2 tiles (conv_halo2_kernel.h):
+// out[((((blk * nch + c) * 9 + tap) * 4 + s) * 64 + lane) * 8 + e] = packed[ch(blk, lane & 31)][c][tap][16 s + 8 (lane >> 5) + e], with
+// MFMA row R = 8 g + 4 h + j of block blk <-> channel 32 blk + 16 (g >> 1) + 8 h + 4 (g & 1) + j (accumulator value 4 g + j of lane half h is
+// element 4 (g & 1) + j of 8-channel chunk 2 (g >> 1) + h: chunk_channel_g<2>, what the shared epilogue stores 16 bytes at a time)
+__global__ void pack_frag32_kernel(const u32x4_t* __restrict__ packed, u32x4_t* __restrict__ out, int cout_pad, int nch) {
+    const int64_t total = (int64_t)cout_pad * nch * 9 * 8;           // 16-byte groups
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        int64_t r = i >> 6;
+        const int s = (int)(r & 3);
+        r >>= 2;
+        const int tap = (int)(r % 9);
+        r /= 9;
+        const int c = (int)(r % nch), blk = (int)(r / nch);
+        const int R = lane & 31, hk = lane >> 5, g = R >> 3, h = (R >> 2) & 1, j = R & 3;
+        const int ch = 32 * blk + 16 * (g >> 1) + 8 * h + 4 * (g & 1) + j;
+        out[i] = packed[(((int64_t)ch * nch + c) * 9 + tap) * 8 + 2 * s + hk];
+    }
+}
+
+int pack_conv_frag32(int dtype, int cout, int cin, const void* packed, void* frag, hipStream_t stream) {
+    Y4_REQUIRE((dtype == Y4_BF16 || dtype == Y4_F16) && cout > 0 && cin > 0 && cin % 64 == 0, Y4_EINVAL,
+               "pack_conv_frag32: 16-bit 3x3 weights with cin %% 64 == 0 (dtype %d, cin %d)", dtype, cin);
+    const int cout_pad = (int)round_up(cout, COUT_PAD), nch = cin / 64;
+    const int64_t total = (int64_t)cout_pad * nch * 9 * 8;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_frag32_kernel, dim3(blocks), dim3(256), 0, stream, (const u32x4_t*)packed, (u32x4_t*)frag, cout_pad, nch);
+    Y4_CHECK_HIP(hipGetLastError());
+    return Y4_OK;
 }
 
 int pack_tail_weights(int dtype, int cout, int cin, const float* oihw, void* packed, hipStream_t stream) {

@@ -688,6 +688,7 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
 // (conv_halo_kernel.h) in conv_halo_<dt>.hip
 int conv_p8_launch(int dtype, int bm, int nst, const ConvK& k, hipStream_t s);
 int conv_halo_launch(int dtype, int bm, int bn, const ConvK& k, hipStream_t s);
+int conv_halo2_launch(int dtype, int tile, const ConvK& k, hipStream_t s);      // conv_halo2_kernel.h, in conv_halo2_<dt>.hip
 
 // plain tiles of one dtype (one translation unit per dtype: conv_igemm_<dt>.hip)
 template <int DT>
@@ -699,6 +700,7 @@ static int launch_plain(int tile, const ConvK& k, hipStream_t s) {
         else if constexpr (DT == Y4_F32 && nst == 32) break;                                  \
         else if constexpr (nst == 8 || nst == 9 || nst == 10) return conv_p8_launch(DT, bm, nst, k, s); \
         else if constexpr (nst == 20) return conv_halo_launch(DT, bm, bn, k, s);              \
+        else if constexpr (nst == 21) return conv_halo2_launch(DT, id, k, s);                 \
         else return launch_cfg<DT, bm, bn, wm, wn, bkb, nst>(k, s);
     switch (tile) { Y4_TILES(Y4_TILE_CASE) }
     set_error("conv2d: tile id %d is not available for this dtype", tile);

@@ -10,7 +10,8 @@ struct TileCfg {
 // id, BM (pixels), BN (channels), WM, WN (wave grid), BKB (bytes of K per LDS row), NST (ring stages, 2..7; 12 = the staggered
 // 2-stage schedule, 32 = 2 stages with the 32x32x16 MFMA; conv_p8_kernel.h: 8 = staggered wave groups, 9 = software-pipelined;
 // 10 = the producer / consumer kernel of conv_l12_kernel.h; 20 = a HALO tile of conv_halo_kernel.h: 3x3 stride-1 convs, BM pixels = a
-// band of full image rows, the input halo tile staged once per 64-channel chunk).
+// band of full image rows, the input halo tile staged once per 64-channel chunk; 21 = a HALO2 tile of conv_halo2_kernel.h: the same band
+// geometry with ONE wave per SIMD, v_mfma_f32_32x32x16 and the weights read straight into registers in MFMA-fragment order).
 // The table is also what tests and the autotuner sweep through y4_conv_desc.tile.
 #define Y4_TILES(X)            \
     X(1, 128, 128, 2, 2, 128, 2)  \
@@ -66,7 +67,14 @@ struct TileCfg {
     X(51, 384, 128, 4, 2, 128, 20) \
     X(52, 192, 256, 2, 4, 128, 20) \
     X(53, 192, 128, 2, 4, 128, 20) \
-    X(54, 320, 128, 4, 2, 128, 20)
+    X(54, 320, 128, 4, 2, 128, 20) \
+    X(55, 384, 128, 2, 2, 128, 21) \
+    X(56, 192, 256, 1, 4, 128, 21) \
+    X(57, 192, 128, 2, 2, 128, 21) \
+    X(58, 384, 64, 2, 2, 64, 21) \
+    X(59, 192, 128, 1, 4, 128, 21) \
+    X(60, 384, 64, 2, 2, 128, 21) \
+    X(61, 384, 128, 2, 2, 64, 21)
 
 #define Y4_TILE_ROW(id, bm, bn, wm, wn, bkb, nst) {bm, bn, wm, wn, bkb, nst},
 static const TileCfg kTiles[] = {Y4_TILES(Y4_TILE_ROW)};
@@ -79,7 +87,7 @@ constexpr int DEEP_TILE1 = 50;
 inline constexpr bool f32_tile(int id) { return id <= F32_TILES || (id >= DEEP_TILE0 && id <= DEEP_TILE1); }
 
 // the tiles that sum in the 32x32x16 MFMA's order (bit-identical among themselves, not with the others)
-inline bool mfma32_tile(int tile) { return tile >= 1 && tile <= kNumTiles && kTiles[tile - 1].nst == 32; }
+inline bool mfma32_tile(int tile) { return tile >= 1 && tile <= kNumTiles && (kTiles[tile - 1].nst == 32 || kTiles[tile - 1].nst == 21); }   // (21: the halo2 tiles, same order)
 
 // tiles the autotuner does not offer: the 32x32x16 ones (another summation order) and the producer / consumer kernel (measured
 // 30-90 % slower than every other form on every layer: kept selectable by id as the record of that experiment)
@@ -114,6 +122,47 @@ inline bool halo_plan(int bm, int bn, int H, int W, HaloPlan* out) {
     const int pitch = (W + 2 + 7) / 8 * 8;
     if (halo_lds_bytes(rows, pitch, bn) > 160 * 1024) return false;
     if ((int64_t)H * W * 4 < (int64_t)bands * bm * 3) return false;      // less than 3/4 of the MFMA tiles' rows would be pixels
+    *out = HaloPlan{rows, bands, pitch};
+    return true;
+}
+
+// Halo2 tiles (conv_halo2_kernel.h): id, BM, BN, WM, WN, KC (channels per staged sub-chunk: LDS rows of 2 KC bytes), OCC (workgroups
+// per CU the kernel is built for: 2 = at most 256 registers and half the LDS).  The same bands as the halo tiles, halo rows at pitch
+// W + 256 / (2 KC) exactly (the y-dependent swizzle that keeps the nine shifted fragment reads free of LDS bank conflicts wants that),
+// two halo buffers of a whole number of 16-row groups, one dummy piece, the touch scratch.  Each of the four waves stages
+// ceil(pieces / 4) <= halo2_pmax one-KB pieces per sub-chunk.
+#define Y4_HALO2_TILES(X)          \
+    X(55, 384, 128, 2, 2, 64, 1)   \
+    X(56, 192, 256, 1, 4, 64, 1)   \
+    X(57, 192, 128, 2, 2, 64, 1)   \
+    X(58, 384, 64, 2, 2, 32, 2)    \
+    X(59, 192, 128, 1, 4, 64, 2)   \
+    X(60, 384, 64, 2, 2, 64, 1)    \
+    X(61, 384, 128, 2, 2, 32, 1)
+struct Halo2Cfg { int id, kc, occ; };
+#define Y4_H2_ROW(id, bm, bn, wm, wn, kc, occ) {id, kc, occ},
+static const Halo2Cfg kHalo2[] = {Y4_HALO2_TILES(Y4_H2_ROW)};
+inline bool halo2_tile(int tile) { return tile >= 1 && tile <= kNumTiles && kTiles[tile - 1].nst == 21; }
+inline const Halo2Cfg* halo2_cfg(int tile) {
+    for (const Halo2Cfg& c : kHalo2) if (c.id == tile) return &c;
+    return nullptr;
+}
+inline constexpr __host__ __device__ int halo2_pmax(int kc, int occ) { return (kc == 32 || occ == 2) ? 10 : 20; }
+inline __host__ __device__ int halo2_rows_alloc(int rows, int pitch) { return ((rows + 2) * pitch + 15) / 16 * 16; }
+inline size_t halo2_lds_bytes(int rows, int pitch, int kc) { return (size_t)2 * halo2_rows_alloc(rows, pitch) * 2 * kc + 1024 + 256; }
+inline bool halo2_plan(int tile, int H, int W, HaloPlan* out) {
+    const Halo2Cfg* hc = halo2_cfg(tile);
+    if (!hc || W < 1 || H < 1) return false;
+    const int bm = kTiles[tile - 1].bm;
+    if (W > bm) return false;
+    int rows = bm / W;
+    if (rows > H) rows = H;
+    const int bands = (H + rows - 1) / rows;
+    rows = (H + bands - 1) / bands;
+    const int pitch = W + 128 / hc->kc;
+    if (halo2_lds_bytes(rows, pitch, hc->kc) > (size_t)(160 * 1024 / hc->occ)) return false;
+    if (((size_t)halo2_rows_alloc(rows, pitch) * 2 * hc->kc / 1024 + 3) / 4 > (size_t)halo2_pmax(hc->kc, hc->occ)) return false;
+    if ((int64_t)H * W * 4 < (int64_t)bands * bm * 3) return false;
     *out = HaloPlan{rows, bands, pitch};
     return true;
 }

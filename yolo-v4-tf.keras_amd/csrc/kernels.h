@@ -46,6 +46,8 @@ int conv_tile_count();
 bool weight_touch_enabled();          // conv_common.h: weight_touch (off with Y4_NO_WEIGHT_TOUCH=1, for A/B runs)
 int conv_pick_tile(int dtype, int M, int cin, int cout);
 int pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw, void* packed, hipStream_t stream);
+// 3x3 packed weights -> MFMA-fragment order of the halo2 tiles (conv_halo2_kernel.h); same byte count
+int pack_conv_frag32(int dtype, int cout, int cin, const void* packed, void* frag, hipStream_t stream);
 
 // misc_kernels.hip
 int stem_conv_launch(int dtype, const void* imgs, int img_u8, int n, int h, int w, const float* wk, const float* scale,

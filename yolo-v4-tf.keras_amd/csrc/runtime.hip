@@ -57,6 +57,8 @@ struct Layer {
     size_t w_off, scale_off, shift_off;   // byte offsets in the wts workspace
     bool has_tail = false;                // a chain can run this 1x1 conv as a tail: its weights are also kept in
     size_t tail_off = 0;                  // fragment order (pack_tail_weights) at this offset
+    bool has_frag = false;                // a 3x3 stride-1 conv the halo2 tiles can run (16-bit, cin % 64 == 0): its weights are also kept
+    size_t frag_off = 0;                  // in MFMA-fragment order (pack_conv_frag32) at this offset
 };
 
 // A run of ops executed as one kernel (conv_chain.h): head = 3x3 conv with residual Add and 64 output channels,
@@ -105,6 +107,8 @@ struct y4_ctx {
     int cells_per_img = 0, cell_base[3] = {0, 0, 0};
     // latency schedules: y4_autotune may pick split-K tile ids (conv_tiles.h); their counters + partial sums live at splitk_off
     bool allow_splitk = false;
+    // y4_autotune may pick halo2 tile ids (conv_halo2_kernel.h: v_mfma_32x32x16, another fp32 summation order than the 16x16x32 tiles)
+    bool allow_halo2 = false;
     // decode's per-image candidate counters are zero (nms_kernel resets them); false: the next decode clears them itself
     bool counts_clean = false;
     int counts_n = 0;
@@ -558,6 +562,8 @@ void layout(y4_ctx& c) {
         L.scale_off = off; off = align256(off + rows * 4);
         L.shift_off = off; off = align256(off + rows * 4);
         if (L.has_tail) { L.tail_off = off; off = align256(off + (size_t)L.d.cout * L.d.cin * c.es); }
+        L.has_frag = c.cfg.dtype != Y4_F32 && L.d.idx > 0 && L.d.ksize == 3 && L.d.stride == 1 && L.d.cin % 64 == 0 && L.fused_with < 0 && L.extra_rows == 0;
+        if (L.has_frag) { L.frag_off = off; off = align256(off + wbytes); }
     }
     if (c.stage_first >= 0) { c.stage_blob_off = off; off = align256(off + csp_stage_blob_bytes()); }
     for (ResRun& r : c.resruns) { r.blob_off = off; off = align256(off + resblock_blob_bytes(r.c)); }
@@ -684,6 +690,7 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
     d.in_cstride = op.in.cstride; d.in_coff = op.in.coff;
     d.out_cstride = op.out.cstride; d.out_coff = op.out.coff;
     d.in = buf_ptr(h, op.in, img0); d.wt = h->wts + L.w_off; d.scale = scale; d.shift = shift;
+    d.wt_frag = L.has_frag ? h->wts + L.frag_off : nullptr;
     d.out = buf_ptr(h, op.out, img0);
     if (op.has_res) { d.res = buf_ptr(h, op.res, img0); d.res_cstride = op.res.cstride; d.res_coff = op.res.coff; }
     if (op.conv2 >= 0) { d.out2 = buf_ptr(h, op.out2, img0); d.out2_cstride = op.out2.cstride; d.out2_coff = op.out2.coff; d.split = op.split; }
@@ -930,6 +937,8 @@ int y4_pack_weights(y4_handle h, const float* blob, size_t n_floats, void* strea
             if (int r = pack_conv_weights(h->cfg.dtype, L.d.cout, L.d.cin, L.d.ksize, w, wdst, s)) return r;
             if (L.has_tail)
                 if (int r = pack_tail_weights(h->cfg.dtype, L.d.cout, L.d.cin, w, h->wts + L.tail_off, s)) return r;
+            if (L.has_frag)
+                if (int r = pack_conv_frag32(h->cfg.dtype, L.d.cout, L.d.cin, wdst, h->wts + L.frag_off, s)) return r;
         }
     }
     if (h->stage_first >= 0) {
@@ -1231,7 +1240,7 @@ static int autotune_impl(y4_handle h, y4_handle h2, int n, int reps, hipStream_t
         for (int tile = 1; tile <= ntiles; ++tile) {
             // the 32x32x16-MFMA tiles sum in another order than all the others: offering them here would make the outputs
             // depend on the tuner's choice.  They are measured slower anyway (LABNOTES.md section 4.1) and stay explicit-only.
-            if (tuner_skips_tile(tile)) continue;
+            if (tuner_skips_tile(tile) && !(h->allow_halo2 && halo2_tile(tile))) continue;
             set_tile(oi, tile);
             const float ms = time_op(oi, images_of(oi), false);
             if (ms == -2.f) { rc = Y4_EHIP; break; }
@@ -1510,6 +1519,13 @@ int y4_set_splitk(y4_handle h, int on) {
     return Y4_OK;
 }
 
+int y4_set_halo2(y4_handle h, int on) {
+    if (int r = check_handle(h)) return r;
+    Y4_REQUIRE(!on || h->cfg.dtype != Y4_F32, Y4_EINVAL, "y4_set_halo2: 16-bit dtypes only");
+    h->allow_halo2 = on != 0;
+    return Y4_OK;
+}
+
 int y4_get_stage_fusion(y4_handle h) {
     if (int r = check_handle(h)) return r;
     return h->stage_active() ? 1 : 0;
@@ -1553,6 +1569,7 @@ int y4_copy_schedule(y4_handle src, y4_handle dst) {
     dst->stage_on = src->stage_on; dst->stage_enabled = src->stage_enabled;
     dst->res_on = src->res_on; dst->res_enabled[0] = src->res_enabled[0]; dst->res_enabled[1] = src->res_enabled[1];
     dst->sub_images = src->sub_images; dst->sub_last_op = src->sub_last_op;
+    dst->allow_halo2 = src->allow_halo2;
     return Y4_OK;
 }
 
@@ -1671,6 +1688,11 @@ int y4_packed_conv_bytes(int dtype, int cout, int cin, int ksize, int32_t* cout_
 int y4_pack_conv_weights(int dtype, int cout, int cin, int ksize, const float* oihw_dev, void* packed_dev, void* stream) {
     Y4_REQUIRE(oihw_dev && packed_dev, Y4_EINVAL, "y4_pack_conv_weights: null pointer");
     return pack_conv_weights(dtype, cout, cin, ksize, oihw_dev, packed_dev, (hipStream_t)stream);
+}
+
+int y4_pack_conv_frag32(int dtype, int cout, int cin, const void* packed_dev, void* frag_dev, void* stream) {
+    Y4_REQUIRE(packed_dev && frag_dev, Y4_EINVAL, "y4_pack_conv_frag32: null pointer");
+    return pack_conv_frag32(dtype, cout, cin, packed_dev, frag_dev, (hipStream_t)stream);
 }
 
 static char* g_zero_page = nullptr;

@@ -71,6 +71,10 @@ class Engine:
         self.grids = [self.img_size // s for s in self.config["strides"]]
         self.nout = 3 * (self.num_classes + 5)
         self.T = self.cfg.max_total
+        self.halo2 = False
+        import os
+        if self.dtype != "f32" and os.environ.get("YOLO4HIP_HALO2", "0") == "1":
+            self.set_halo2(True)          # (experiments: `autotune` may pick the halo2 tiles; shipped schedules that hold them need no switch)
 
     def sibling(self):
         """A second handle on the same GPU that SHARES this engine's packed weights (read-only) and owns a second activation
@@ -646,6 +650,13 @@ class Engine:
         default, and the schedules that ship for batch 1 say so (`"splitk": true`)."""
         ext.check(self.lib.y4_set_splitk(self.handle, int(bool(on))))
         self.splitk = bool(on)
+
+    def set_halo2(self, on=True):
+        """Let `autotune` also offer the halo2 tiles (conv_halo2_kernel.h: one wave per SIMD, v_mfma_32x32x16, weights in registers)
+        for the 3x3 stride-1 convs.  They sum the K axis in another fixed fp32 order than the 16x16x32 tiles, so -- as with split-K --
+        a schedule that holds them (`"halo2": true`) is part of the numerical result and is tested against the oracle."""
+        ext.check(self.lib.y4_set_halo2(self.handle, int(bool(on))))
+        self.halo2 = bool(on)
 
     def set_subbatch(self, images, last_conv=16):
         """Run convs 0..last_conv over `images` images at a time (Infinity-Cache residency of the big early

@@ -45,7 +45,7 @@ class y4_conv_desc(C.Structure):
                 ("res_cstride", C.c_int32), ("res_coff", C.c_int32), ("in_", C.c_void_p), ("wt", C.c_void_p),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("res", C.c_void_p), ("out", C.c_void_p),
                 ("tile", C.c_int32), ("out2", C.c_void_p), ("out2_cstride", C.c_int32), ("out2_coff", C.c_int32),
-                ("split", C.c_int32), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t)]
+                ("split", C.c_int32), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t), ("wt_frag", C.c_void_p)]
 
 
 # every symbol include/yolo4hip.h declares: name -> (restype, argtypes)
@@ -92,10 +92,12 @@ SYMBOLS = {
     "y4_timing_end": (_I, [_VP, _VP, _VP, _I, C.POINTER(_I), C.POINTER(_I), _VP]),
     "y4_packed_conv_bytes": (_I, [_I, _I, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
     "y4_pack_conv_weights": (_I, [_I, _I, _I, _I, _VP, _VP, _VP]),
+    "y4_pack_conv_frag32": (_I, [_I, _I, _I, _VP, _VP, _VP]),
     "y4_conv2d": (_I, [C.POINTER(y4_conv_desc), _VP]),
     "y4_conv_tile_count": (_I, []),
     "y4_conv_tile_desc": (_I, [_I, C.POINTER(C.c_int32)]),
     "y4_set_splitk": (_I, [_VP, _I]),
+    "y4_set_halo2": (_I, [_VP, _I]),
     "y4_pack_stem_weights": (_I, [_VP, _VP, _I, _VP]),
     "y4_stem_conv": (_I, [_I, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _I, _VP]),
     "y4_preprocess_u8": (_I, [_VP, _I, _I, _VP, _I, _I, _VP]),
