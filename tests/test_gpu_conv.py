@@ -164,7 +164,7 @@ def test_halo_tiles_vs_oracle_and_bit_identical(case, dtype):
 HALO2_CASES = HALO_CASES + [
     (38, 256, 512, 2, "mish", False, (0, 0), (0, 0)),         # the plan's 3x3 256 -> 512 @38^2: four chunks, four channel tiles
     (19, 512, 512, 3, "mish", True, (0, 0), (0, 0)),          # eight chunks, residual Add, 19 x 21 / 19 x 23 halo rows
-    (20, 128, 128, 3, "linear", False, (0, 0), (0, 0)),       # even width that is no stage of the plan; the general epilogue
+    (24, 128, 128, 3, "linear", False, (0, 0), (0, 0)),       # a width that is no stage of the plan; the general (linear) epilogue
     (52, 128, 256, 1, "leaky", False, (64, 64), (128, 0)),    # 416 / 8; channel slices on both sides
 ]
 
