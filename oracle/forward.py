@@ -42,7 +42,7 @@ def _round_storage(t, storage):
 
 
 class _Net:
-    def __init__(self, weights, dtype, collect=None, storage=None):
+    def __init__(self, weights, dtype, collect=None, storage=None, trunk=None):
         self.weights = weights
         self.dtype = dtype
         self.i = 0
@@ -53,6 +53,11 @@ class _Net:
         # epilogue (one rounding of the sum), raw heads kept in float32 -- to separate what 16-bit STORAGE costs (this
         # emulation vs the fp32 oracle) from what the kernels add on top (HIP vs this emulation).  Not a reference behaviour.
         self.storage = storage
+        # trunk = 'f32' | 'f16' (with storage = 'bf16'): price a WIDER residual trunk -- the tensor `x` of residual_block
+        # (custom_layers.py:34-44) carried from Add to Add in float32 / float16 beside its 16-bit rounding, which is what the
+        # convs keep consuming.  A diagnostic of what the 23 Adds' roundings cost, not a reference behaviour.
+        self.trunk = trunk
+        self._wide = None
         self._defer_round = False
 
     # custom_layers.py:5-31
@@ -92,7 +97,14 @@ class _Net:
         self._defer_round = True                      # storage emulation: the sum is rounded, not the branch
         y = self.conv(y, filters2, 3, activation=activation)
         self._defer_round = False
-        out = _round_storage(x + y, self.storage)
+        if self.trunk is not None and self.storage is not None:
+            wide = (self._wide if self._wide is not None else x) + y
+            if self.trunk == "f16":
+                wide = wide.to(torch.float16).to(torch.float32)
+            self._wide = wide
+            out = _round_storage(wide, self.storage)
+        else:
+            out = _round_storage(x + y, self.storage)
         if (self.i - 1) in self.collect:
             self.taps[("add", self.i - 1)] = out      # what the HIP path stores for this conv (Add fused)
         return out
@@ -101,9 +113,11 @@ class _Net:
     def csp_block(self, x, residual_out, repeat, residual_bottleneck=False):
         route = self.conv(x, residual_out, 1, activation="mish")
         x = self.conv(x, residual_out, 1, activation="mish")
+        self._wide = None                             # (a wider trunk starts at the stage's main-in conv output, as stored)
         for _ in range(repeat):
             x = self.residual_block(x, residual_out // 2 if residual_bottleneck else residual_out,
                                     residual_out, activation="mish")
+        self._wide = None
         x = self.conv(x, residual_out, 1, activation="mish")
         return torch.cat([x, route], dim=1)
 
@@ -185,7 +199,7 @@ class _Net:
         return [conv_sbbox, conv_mbbox, conv_lbbox]
 
 
-def yolo_model_forward(imgs_nhwc, weights, num_classes, dtype=torch.float32, collect=None, threads=None, storage=None):
+def yolo_model_forward(imgs_nhwc, weights, num_classes, dtype=torch.float32, collect=None, threads=None, storage=None, trunk=None):
     """`yolo_model.predict(imgs)` (`models.py:50-52`): NHWC float images in [0,1] -> list of 3 NHWC
     arrays [N,H/8,W/8,3(C+5)], [N,H/16,..], [N,H/32,..] (raw logits).  With `collect=[conv idx...]`
     also returns {idx: NHWC array of that conv's post-activation output}.  `storage` ('bf16' | 'f16'): emulate the 16-bit
@@ -195,7 +209,7 @@ def yolo_model_forward(imgs_nhwc, weights, num_classes, dtype=torch.float32, col
     x = torch.from_numpy(np.ascontiguousarray(imgs_nhwc)).to(dtype)      # Keras casts to float32
     x = _round_storage(x, storage)                      # the stem's MFMA operand is 16-bit
     x = x.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
-    net = _Net(weights, dtype, collect, storage)
+    net = _Net(weights, dtype, collect, storage, trunk)
     with torch.no_grad():
         outs = net.yolov4_neck(x, num_classes)
     assert net.i == len(weights) == 110, net.i

@@ -80,6 +80,9 @@ __device__ unsigned long long h2_trace_blocks[4096][4];        // per workgroup 
 #define H2_STAMP_RT(slot) do { } while (0)
 #endif
 
+#ifndef H2_LOOP_PRIO
+#define H2_LOOP_PRIO 2
+#endif
 #ifndef HALO2_ABLATIONS
 // 1 (kernel experiments only): the HALO_ABL environment variable then switches parts of the K loop off at run time -- bit 1 the
 // weight loads, 2 the halo pieces, 4 the fragment reads, 8 the barrier -- for TIMING; results are wrong.  Not in the regular build.
@@ -241,6 +244,9 @@ __global__ __launch_bounds__(256, OCC) void conv_halo2_kernel(const ConvK p) {
     }
 
     const int nsteps = nchunks * 36;
+    // Two workgroups per CU = two waves per SIMD: the one in its K loop must win the issue arbitration against the one in its
+    // prologue / epilogue (plain age order lets an older wave's Mish epilogue starve the younger wave's MFMA stream of VALU slots)
+    if constexpr (OCC == 2) __builtin_amdgcn_s_setprio(H2_LOOP_PRIO);
     for (int c = 0; c < nchunks; ++c) {
         h2_static_for<0, 36>([&](auto sgc) __attribute__((always_inline)) {
             constexpr int sg = decltype(sgc)::value;
@@ -312,6 +318,7 @@ __global__ __launch_bounds__(256, OCC) void conv_halo2_kernel(const ConvK p) {
     }
     // (every weight load past the end was an out-of-range dummy; nothing of this kernel is in flight that writes a register)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (OCC == 2) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     H2_STAMP(12);
 

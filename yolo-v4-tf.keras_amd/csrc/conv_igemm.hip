@@ -191,7 +191,10 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
         k.h_rows = hp.rows; k.h_bands = hp.bands; k.h_pitch = hp.pitch;
         k.h_div_pitch = fastdiv_make((uint32_t)hp.pitch); k.h_div_bands = fastdiv_make((uint32_t)hp.bands);
         k.grid_m = d->n * hp.bands;
-        k.h_xmap = wt_bytes > ((int64_t)3 << 20) ? 1 : 0;
+        // (the halo kernel's XCD <-> channel tile map for weights larger than an L2 is OFF here: these kernels look two taps ahead for their
+        //  weights, and measured L2-cold -- as in a step -- the map costs 512 -> 1024 @19^2 88 -> 106 us and 256 -> 512 @38^2 95 -> 100;
+        //  Y4_H2_XMAP=1 turns it on for experiments)
+        { static const int xm = [] { const char* e = getenv("Y4_H2_XMAP"); return e ? atoi(e) : 0; }(); k.h_xmap = xm; }
         { static const int abl = [] { const char* e = getenv("HALO_ABL"); return e ? atoi(e) : 0; }(); k.h_abl = abl; }      // (read only by a -DHALO2_ABLATIONS=1 build)
     }
     Y4_REQUIRE((int64_t)k.grid_n * tc.bn <= cout_pad, Y4_EINVAL, "conv2d: tile %d overruns the packed weight rows", tile);

@@ -74,7 +74,8 @@ struct TileCfg {
     X(58, 384, 64, 2, 2, 64, 21) \
     X(59, 192, 128, 1, 4, 128, 21) \
     X(60, 384, 64, 2, 2, 128, 21) \
-    X(61, 384, 128, 2, 2, 64, 21)
+    X(61, 384, 128, 2, 2, 64, 21) \
+    X(62, 192, 128, 2, 2, 64, 21)
 
 #define Y4_TILE_ROW(id, bm, bn, wm, wn, bkb, nst) {bm, bn, wm, wn, bkb, nst},
 static const TileCfg kTiles[] = {Y4_TILES(Y4_TILE_ROW)};
@@ -138,7 +139,8 @@ inline bool halo_plan(int bm, int bn, int H, int W, HaloPlan* out) {
     X(58, 384, 64, 2, 2, 32, 2)    \
     X(59, 192, 128, 1, 4, 64, 2)   \
     X(60, 384, 64, 2, 2, 64, 1)    \
-    X(61, 384, 128, 2, 2, 32, 1)
+    X(61, 384, 128, 2, 2, 32, 1)   \
+    X(62, 192, 128, 2, 2, 32, 1)
 struct Halo2Cfg { int id, kc, occ; };
 #define Y4_H2_ROW(id, bm, bn, wm, wn, kc, occ) {id, kc, occ},
 static const Halo2Cfg kHalo2[] = {Y4_HALO2_TILES(Y4_H2_ROW)};
