@@ -144,14 +144,6 @@ def combined_nms(boxes, scores, max_output_size_per_class=100, max_total_size=10
     return out_b, out_s, out_c, out_v, out_i
 
 
-def decision_margins(boxes, scores, kept_idx, kept_cls, iou_threshold=0.413, score_threshold=0.3):
-    """Smallest |score - score_threshold| over all (box, class) and smallest |IoU - iou_threshold| of any
-    same-class candidate pair, for one image.  Parity tests assert identical kept indices only when these
-    margins exceed the float noise of the forward pass (documented in the test)."""
-    s = np.abs(scores.astype(np.float64) - float(F32(score_threshold)))
-    return float(s.min())
-
-
 def inference_from_heads(outputs, num_classes, anchors, xyscale, input_size, strides=(8, 16, 32),
                          iou_threshold=0.413, score_threshold=0.3, max_boxes=100):
     """`inference_model` tail (`models.py:68-73`): raw heads -> the 4 NMS outputs (+ kept_idx)."""

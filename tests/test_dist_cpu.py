@@ -64,6 +64,39 @@ def _worker(rank, world, port, ret):
     sched = D.share_schedule({"tiles": list(range(110)), "stage_fusion": True, "res_fusion_mask": 5} if rank == 0 else {"tiles": [rank]})
     assert sched == {"tiles": list(range(110)), "stage_fusion": True, "res_fusion_mask": 5}
     assert D.share_schedule(None if rank == 0 else {"tiles": [1]}) is None
+    # 6. Engine.ensure_schedule(share=True) on a stand-in engine (no GPU here): the schedule reaches every rank and is applied there;
+    #    a rank 0 that raises while resolving broadcasts the failure (the others raise instead of hanging in the collective); an
+    #    engine of another shape than rank 0's refuses rank 0's tile ids
+    from yolo4hip.engine import Engine
+
+    class Fake:
+        img_size, num_classes, max_batch, dtype = 608, 80, 32, "bf16"
+        used = None
+        fail = False
+        def _resolve_schedule(self, tune):
+            if self.fail:
+                raise ValueError("tuning ran out of memory")
+            return "shipped", "/x.json", {"tiles": [7] * 110}
+        def _use_schedule(self, saved): self.used = saved
+        def say_schedule(self): pass
+    f = Fake()
+    src, _ = Engine.ensure_schedule(f, tune=True, verbose=False, share=True)
+    assert src == ("shipped" if rank == 0 else "shared") and (rank == 0 or f.used == {"tiles": [7] * 110})
+    f = Fake(); f.fail = True
+    try:
+        Engine.ensure_schedule(f, tune=True, verbose=False, share=True)
+        raised = False
+    except RuntimeError as e:
+        raised = "rank 0 could not resolve" in str(e) and "out of memory" in str(e)
+    assert raised
+    f = Fake()
+    if rank == world - 1:
+        f.max_batch = 8
+    try:
+        Engine.ensure_schedule(f, tune=True, verbose=False, share=True)
+        assert rank != world - 1, "a schedule for another batch size was applied"
+    except RuntimeError as e:
+        assert rank == world - 1 and "every rank must build the same engine" in str(e)
     D.barrier()
     ret[rank] = (ok_bcast, ok_gather, mx, mxs)
     torch.distributed.destroy_process_group()

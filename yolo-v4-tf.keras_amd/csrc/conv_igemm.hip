@@ -73,6 +73,9 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
     const int epc = 16 / es;
     Y4_REQUIRE(d->cin % (64 / es) == 0, Y4_EINVAL, "conv2d: cin %d must be a multiple of %d for dtype %d",
                d->cin, 64 / es, d->dtype);
+    Y4_REQUIRE(d->cin % k_chunk_channels(d->cin, d->ksize) == 0, Y4_EINVAL,
+               "conv2d: cin %d is not a whole number of %d-channel K chunks (the canonical K order of a 3x3 conv, common.h)", d->cin,
+               k_chunk_channels(d->cin, d->ksize));
     Y4_REQUIRE(d->in_cstride % epc == 0 && d->in_coff % epc == 0, Y4_EINVAL, "conv2d: input view not 16-byte aligned");
     const int oepc = d->out_f32 ? 4 : epc;
     Y4_REQUIRE(d->out_cstride % oepc == 0 && d->out_coff % oepc == 0, Y4_EINVAL,
@@ -90,9 +93,13 @@ int conv2d_launch(const y4_conv_desc* d, const char* zero_page, hipStream_t stre
     k.K = d->ksize * d->ksize * d->cin;
     const int64_t in_bytes = (int64_t)d->n * d->h * d->w * d->in_cstride * es;
     const int64_t wt_bytes = (int64_t)round_up(d->cout, COUT_PAD) * k.K * es;
-    Y4_REQUIRE(in_bytes < (1ll << 31) && wt_bytes < (1ll << 31), Y4_EINVAL,
-               "conv2d: input (%lld B) or weights (%lld B) exceed the 2 GiB buffer-descriptor range", (long long)in_bytes,
-               (long long)wt_bytes);
+    // (the implicit-GEMM kernels address the input through a descriptor based one row + one pixel BEFORE it, with row offsets biased by
+    //  the same amount and taps up to two rows + two pixels further: all of that must stay below 2^31 too, or an out-of-range padding
+    //  offset would wrap into range -- ADVICE r5)
+    const int64_t tap_span = d->ksize == 3 ? ((int64_t)3 * d->w + 3) * d->in_cstride * es + (int64_t)d->cin * es : 0;
+    Y4_REQUIRE(in_bytes + tap_span < (1ll << 31) && wt_bytes < (1ll << 31), Y4_EINVAL,
+               "conv2d: input (%lld B + %lld B of tap reach) or weights (%lld B) exceed the 2 GiB buffer-descriptor range", (long long)in_bytes,
+               (long long)tap_span, (long long)wt_bytes);
     k.in_bytes = (unsigned)in_bytes; k.wt_bytes = (unsigned)wt_bytes;
     {   // extents of the views the fast epilogue addresses through buffer descriptors (conv_common.h: conv_epilogue_fast)
         const int64_t ob = (int64_t)k.M * d->out_cstride * es, ob2 = d->out2 ? (int64_t)k.M * d->out2_cstride * es : 0,

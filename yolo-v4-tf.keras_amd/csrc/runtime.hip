@@ -673,7 +673,9 @@ int run_op(y4_handle h, const Op& op, const void* imgs, int n, hipStream_t s, in
         // the conv kernels address their input through a raw buffer descriptor (2 GiB range, conv_igemm.hip): a batch
         // whose input view is larger runs as consecutive image chunks of this same op (images are independent)
         const int64_t per_img = (int64_t)op.in.side * op.in.side * op.in.cstride * h->es;
-        const int max_n = (int)(((1ll << 31) - 1) / per_img);
+        // (minus the reach of a 3x3 kernel's biased tap offsets: conv2d_launch's own check)
+        const int64_t tap_span = L.d.ksize == 3 ? ((int64_t)3 * op.in.side + 3) * op.in.cstride * h->es + (int64_t)op.in.c * h->es : 0;
+        const int max_n = (int)(((1ll << 31) - 1 - tap_span) / per_img);
         Y4_REQUIRE(max_n >= 1, Y4_EINVAL, "conv %d: one image's input (%lld B) exceeds the 2 GiB buffer-descriptor range",
                    op.conv, (long long)per_img);
         if (n > max_n) {
@@ -906,7 +908,10 @@ int y4_bind_workspace(y4_handle h, void* act_dev, size_t act_bytes, void* wts_de
     h->weights_ready = false;
     // The WHOLE activation workspace starts as zeros (round 5; once per bind, ~1 ms per 3 GB): the zero page, the NMS status word and
     // the split-K tile counters (zero between launches) need it, and no result can then depend on what the caller's memory held
-    // before -- a workspace from a caching allocator carries the previous owner's tensors.
+    // before -- a workspace from a caching allocator carries the previous owner's tensors.  The previous owner's WORK too: kernels still
+    // pending on some non-blocking stream against the recycled block would land after a null-stream memset, so the
+    // device is drained first -- binding is an init-time call.
+    Y4_CHECK_HIP(hipDeviceSynchronize());
     Y4_CHECK_HIP(hipMemset(h->act, 0, h->act_bytes));
     // ... and it HAS happened when this returns: the caller may use the handle on any stream next, and a non-blocking stream (every
     // torch.cuda.Stream is one) does not order itself behind the null stream the memset ran on

@@ -37,7 +37,7 @@ class _KerasLikeModel:
 
 class Yolov4(object):
     def __init__(self, weight_path=None, class_name_path='coco_classes.txt', config=yolo_config, *,
-                 dtype='f32', max_batch=32, synth_seed=0, device=None, device_preprocess=True, tune=None):
+                 dtype='f32', max_batch=32, synth_seed=0, device=None, device_preprocess=True, tune=None, share_schedule=None):
         assert config['img_size'][0] == config['img_size'][1], 'not support yet'
         assert config['img_size'][0] % config['strides'][-1] == 0, 'must be a multiple of last stride'
         self.class_names = [line.strip() for line in open(class_name_path).readlines()]
@@ -59,8 +59,12 @@ class Yolov4(object):
         # images: seconds at 160^2, ~20 s at 608^2 x 32; written to $YOLO4HIP_CACHE, default ~/.cache/yolo4hip):
         #   tune=None (default)  on the first predict of this object, not in the constructor; YOLO4HIP_TUNE=0: never
         #   tune=True            now, in the constructor          tune=False   never (built-in tile heuristic)
-        # Under an initialised torch.distributed group of more than one rank the constructor is a COLLECTIVE: rank 0 resolves
-        # (and, if allowed, tunes) the schedule now and broadcasts it, so every rank runs the same tile set.
+        # share_schedule=True (or YOLO4HIP_SHARE_SCHEDULE=1) under an initialised torch.distributed group of more than one rank makes
+        # the constructor a COLLECTIVE -- rank 0 resolves (and, if allowed, tunes) the schedule now and broadcasts it, so every rank
+        # runs the same tile set after ONE tuning run; every rank must then construct the same model.  Off by default (a
+        # model built on some ranks only -- a rank-0 evaluation inside a DDP job -- must not block in a broadcast): each rank then
+        # resolves its own schedule, which for shipped and cached schedules is the same file everywhere.
+        self._share_schedule = (os.environ.get('YOLO4HIP_SHARE_SCHEDULE', '0') == '1') if share_schedule is None else bool(share_schedule)
         self._tune = (os.environ.get('YOLO4HIP_TUNE', '1') != '0') if tune is None else bool(tune)
         self._tune_eager = tune is True
         self.build_model(load_pretrained=True if self.weight_path else False)
@@ -85,7 +89,7 @@ class Yolov4(object):
         # ids are bit-identical scheduling choices (tests/test_gpu_forward.py), so WHEN the tuning happens changes no result.
         from . import dist as D
         self._tune_pending = False
-        if D.group_rank_world()[1] > 1:
+        if self._share_schedule and D.group_rank_world()[1] > 1:
             self.schedule_source = self.engine.ensure_schedule(tune=self._tune, share=True)
         elif self._tune_eager or not self._tune:
             self.schedule_source = self.engine.ensure_schedule(tune=self._tune)

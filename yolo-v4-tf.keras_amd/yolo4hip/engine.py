@@ -512,10 +512,11 @@ class Engine:
         """The tuned schedule that ships with the package for this (image side, classes, batch, dtype), or None: the
         per-launch tile ids, the stage-kernel switch and the residual-block mask one `autotune` run chose on an MI355X
         (`yolo4hip/schedules/<side>_<classes>_<batch>_<dtype>.json`; the headline shape's file IS `profiles/r03/tiles.json`,
-        the set the committed PMC passes profiled).  A schedule WITHOUT split-K ids (`"splitk": false`, every batch > 2 file) is a
-        pure scheduling choice: every such choice gives the same bits.  The batch-1 files carry split-K ids (`"splitk": true`):
-        they sum the K loop in another, fixed fp32 order -- the same on every machine because the file is the same -- and are held
-        to the oracle instead (tests/test_gpu_forward.py::test_splitk_latency_schedule_vs_oracle)."""
+        the set the committed PMC passes profiled).  A schedule WITHOUT split-K or halo2 ids (`"splitk": false`, `"halo2": false`) is a
+        pure scheduling choice: every such choice gives the same bits.  The batch-1 files carry split-K ids (`"splitk": true`), the
+        batch-32 / 64 16-bit files since round 6 halo2 ids (`"halo2": true`: tile ids 55-62, conv_halo2_kernel.h, v_mfma_32x32x16):
+        those sum the K loop in another, fixed fp32 order -- the same on every machine because the file is the same -- and are held
+        to the oracle instead (tests/test_gpu_forward.py::test_splitk_latency_schedule_vs_oracle, tests/test_gpu_parity_full.py)."""
         import json
         import os
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "schedules",
@@ -548,19 +549,35 @@ class Engine:
         loaded.  Every schedule without split-K ids gives the same bits; one with them is tested against the oracle instead
         (`"splitk": true` in the file).  `share=True` under an initialised torch.distributed group makes the call a COLLECTIVE:
         rank 0 resolves (1)-(3), the others take rank 0's schedule from a broadcast (source 'shared') -- one tuning run per job,
-        the same tile set on every rank.  The tuned schedule is judged one batch at a time (`"in_flight": 1`) even
+        the same tile set on every rank.  EVERY rank of the group must make the call, with the same (size, classes,
+        batch, dtype): the shape travels with the schedule and a mismatch raises; a rank 0 that fails to resolve broadcasts the
+        failure, so the others raise instead of waiting for the process group's timeout.  The tuned schedule is judged one batch at a time (`"in_flight": 1`) even
         when `predict_stream` later keeps two in flight; `bench.py --pair-passes` / `y4_autotune_pair` is the pair-judged variant.
         Returns (source, path): source in 'shipped' | 'cached' | 'tuned' | 'shared' | 'heuristic' (tune=False and nothing found)."""
         from . import dist as D
         rank, world = D.group_rank_world() if share else (0, 1)
-        src, path, saved = "heuristic", None, None
+        src, path, saved, err = "heuristic", None, None, None
+        mine = [int(self.img_size), int(self.num_classes), int(self.max_batch), str(self.dtype)]
         if rank == 0:
-            src, path, saved = self._resolve_schedule(tune)
+            try:
+                src, path, saved = self._resolve_schedule(tune)
+            except Exception as e:                     # (a rank 0 that raised before the broadcast would leave the others hanging in it)
+                if world == 1:
+                    raise
+                err = f"{type(e).__name__}: {e}"
         if world > 1:
-            saved = D.share_schedule(saved, src=0)
-            if rank != 0 and saved is not None:
-                self._use_schedule(saved)
-                src, path = "shared", None
+            got = D.share_schedule({"schedule": saved, "error": err, "shape": mine} if rank == 0 else None, src=0)
+            if got is None or got.get("error"):
+                raise RuntimeError("ensure_schedule(share=True): rank 0 could not resolve a schedule" +
+                                   (f" ({got['error']})" if got else ""))
+            if rank != 0:
+                if list(got["shape"]) != mine:
+                    raise RuntimeError(f"ensure_schedule(share=True): rank 0 resolved a schedule for (size, classes, batch, dtype) = "
+                                       f"{tuple(got['shape'])}, this rank's engine is {tuple(mine)} -- every rank must build the same engine")
+                saved = got["schedule"]
+                if saved is not None:
+                    self._use_schedule(saved)
+                    src, path = "shared", None
         self.schedule_source = (src, path)
         if verbose:
             self.say_schedule()
@@ -620,6 +637,7 @@ class Engine:
                  "tiles": tiles, "stage_fusion": bool(self.stage_fusion_active()) if self.dtype != "f32" else False,
                  "res_fusion_mask": int(self.res_fusion_mask()) if self.dtype != "f32" else 0, "in_flight": 1,
                  "splitk": any(abs(t) % 1000 >= 100 or abs(t) // 1000 >= 100 for t in tiles),
+                 "halo2": bool(getattr(self, "halo2", False)) and any(55 <= abs(t) % 100 <= 62 for t in tiles),
                  "tuned_on": torch.cuda.get_device_properties(self.device).gcnArchName}
         try:
             os.makedirs(os.path.dirname(path), exist_ok=True)

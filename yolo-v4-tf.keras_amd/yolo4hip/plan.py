@@ -15,7 +15,7 @@ Reference behaviours reproduced on purpose:
 Generalised on purpose: grid sizes are img_size // stride instead of the hard-coded 52/26/13
 (`custom_layers.py:204,208,212`), which is what lets the 608x608 configs exist at all.
 
-The C++ runtime (csrc/plan.cpp) builds the same table independently; tests compare the two through
+The C++ runtime (csrc/runtime.hip: build_plan) builds the same table independently; tests compare the two through
 `y4_layer_info`.
 """
 from dataclasses import dataclass, field
