@@ -80,6 +80,9 @@ __device__ unsigned long long h2_trace_blocks[4096][4];        // per workgroup 
 #define H2_STAMP_RT(slot) do { } while (0)
 #endif
 
+#ifndef H2_NOP
+#define H2_NOP -1               // >= 0: an `s_nop H2_NOP` behind every MFMA of the K loop (experiments only; see there)
+#endif
 #ifndef H2_LOOP_PRIO
 #define H2_LOOP_PRIO 2
 #endif
@@ -204,7 +207,11 @@ __global__ __launch_bounds__(256, OCC) void conv_halo2_kernel(const ConvK p) {
         //  256-register K loop does not have: the optimiser then spills them and drains the whole load queue (vmcnt(0)) at every reload.
         //  With 512 registers they ARE hoisted, which is worth 10 % of the loop: 33.5 against 36.8 cycles per MFMA)
         int rr = r0[i];
+#if defined(H2_DBG) && H2_DBG == 3
+        asm volatile("" : "+v"(rr));
+#else
         if constexpr (OCC == 2) asm volatile("" : "+v"(rr));
+#endif
         const int r = rr + ky * P + kx;                   // (brow % 16 == 0: the swizzle does not see the buffer)
         const int e = ((r >> SH) - yq[i] - ky) ^ fh;
         return smem_u + (unsigned)((r + brow) * RB + ((e & (CPR - 1)) << 4));
@@ -252,14 +259,18 @@ __global__ __launch_bounds__(256, OCC) void conv_halo2_kernel(const ConvK p) {
             constexpr int sg = decltype(sgc)::value;
             constexpr int sb = sg / SUB, ls = sg % SUB, cur = (sg & 1) % XS, nxt = (cur + 1) % XS;            // sub-chunk of the chunk, k-step in it
             // -- this k-step's weights (loaded AHEAD k-steps ago): VMEM instructions issued since = the NB loads of each of the
-            //    AHEAD-1 k-steps between, plus the one halo piece of every k-step among them that carries one (in a k-step the piece
-            //    follows the weight loads, so k-step sg - AHEAD's own piece is younger than the loads waited for)
+            //    AHEAD-1 k-steps between, plus the one halo piece of every k-step among them that carries one.  In a k-step the piece goes
+            //    out IN FRONT of the weight loads, so the piece of k-step sg - AHEAD is older than the loads waited for here: at the last
+            //    k-step of a sub-chunk (SUB - 1) every piece of k-steps 0 .. SUB - 1 - AHEAD -- all of them, PMAX <= SUB - AHEAD -- has landed
             constexpr int younger = [] {
                 auto piece = [](int q) { return ((q + 36) % SUB) < PMAX ? 1 : 0; };
-                int y = piece(sg - AHEAD);
+                int y = 0;
                 for (int q = sg - (AHEAD - 1); q < sg; ++q) y += NB + piece(q);
                 return y;
             }();
+#if defined(H2_DBG) && H2_DBG == 4
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
             h2_wait_vm_n<younger>();
 #pragma unroll
             for (int j = 0; j < NB; ++j) h2_landed(wf[sg % RING][j]);
@@ -283,6 +294,11 @@ __global__ __launch_bounds__(256, OCC) void conv_halo2_kernel(const ConvK p) {
                 constexpr int m = decltype(mc)::value;
                 constexpr int j = m / MB, i = m - j * MB;     // channel block outer
                 Mma32<DT>::run(acc[i][j], wf[sg % RING][j], xf[cur][i]);
+                // (experiment switch, off: an s_nop behind every MFMA.  While the bug fixed behind the K loop -- re-used destinations of
+                //  loads still in flight -- was being hunted, such a nop made the failures vanish, which looked like a write-after-read
+                //  hazard on the MFMA's source registers; it only moved the register allocation.  With the real fix in, the kernel is
+                //  clean with and without it: 0 differing launches of 3 600 / 0 of 600 forwards either way, scripts/h2_stress.py, h2_det.py)
+                if constexpr (H2_NOP >= 0) asm volatile("s_nop %0" ::"n"(H2_NOP >= 0 ? H2_NOP : 0) : "memory");
                 // filler work of this gap
                 if constexpr (m < MB) {
                     if (!(HALO2_ABLATIONS && (p.h_abl & 4))) {
@@ -295,18 +311,18 @@ __global__ __launch_bounds__(256, OCC) void conv_halo2_kernel(const ConvK p) {
                     }
                 }
                 {
-                    // the NB weight loads and the halo piece go into the gaps after the reads (or share the last gaps when there are few)
+                    // the halo piece and then the NB weight loads go into the gaps after the reads (or share the last gaps when there are few)
                     constexpr int first = NMMA - MB >= NB + 1 ? MB : (NMMA - (NB + 1));
-                    constexpr int slot = m - first;
+                    constexpr int slot = m - first - 1;
+                    if constexpr (slot == -1 && ls < PMAX) {
+                        if (!(HALO2_ABLATIONS && (p.h_abl & 2))) stage_piece(ls, st_buf, (cc + 1) * RB, cc + 1 < nchunks * NSUB);
+                    }
                     if constexpr (slot >= 0 && slot < NB) {
                         if (!(HALO2_ABLATIONS && (p.h_abl & 1))) {
                             // weights of k-step sg + AHEAD into the ring slot k-step sg - 1 has just finished with
                             const int v = c * 36 + sg + AHEAD < nsteps ? wv[slot] + w_hi(sg + AHEAD) : (int)0x80000000;      // (past the end: nothing to load, same count)
                             h2_wload_n<w_lo(sg + AHEAD)>(wf[(sg + AHEAD) % RING][slot], v, rs_w);
                         }
-                    }
-                    if constexpr (slot == NB && ls < PMAX) {
-                        if (!(HALO2_ABLATIONS && (p.h_abl & 2))) stage_piece(ls, st_buf, (cc + 1) * RB, cc + 1 < nchunks * NSUB);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -316,8 +332,25 @@ __global__ __launch_bounds__(256, OCC) void conv_halo2_kernel(const ConvK p) {
         for (int j = 0; j < NB; ++j) wv[j] += 36864;
         H2_STAMP(3 + (c < 8 ? c : 8));
     }
-    // (every weight load past the end was an out-of-range dummy; nothing of this kernel is in flight that writes a register)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The last AHEAD k-steps' weight loads (out-of-range dummies) and the last fragment reads are still in flight, and their destination
+    // registers are dead as far as the compiler can see: without the statements below it re-used them for the epilogue's first
+    // temporaries ABOVE the wait (an asm output counts as written at the statement) and a load that landed late then overwrote an
+    // accumulator value on its way through such a temporary -- a few elements of a launch wrong, only when the memory system was slow
+    // (tests/test_gpu_determinism.py under a second stream's load).  Every ring register is therefore "used" once more BEHIND the wait.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < RING; ++r)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) h2_landed(wf[r][j]);
+#pragma unroll
+    for (int x = 0; x < XS; ++x)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) h2_landed(xf[x][i]);
+#if defined(H2_DBG) && H2_DBG == 1
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#elif defined(H2_DBG) && H2_DBG == 2
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     if constexpr (OCC == 2) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     H2_STAMP(12);
