@@ -1,8 +1,8 @@
 #!/bin/bash
-# Collects the measurement set committed under profiles/r05 (run on the GPU box, from the repo root), ONCE per round:
-#   rm -rf gpurun_out/r5set                 # LOCALLY first: gpurun merges into gpurun_out/
+# Collects the measurement set committed under profiles/r06 (run on the GPU box, from the repo root), ONCE per round:
+#   rm -rf gpurun_out/r6set                 # LOCALLY first: gpurun merges into gpurun_out/
 #   gpurun --timeout 2700 -- 'Y4_COLLECT_TILES=yolo-v4-tf.keras_amd/yolo4hip/schedules/608_80_32_bf16.json bash scripts/collect_profiles.sh'
-# Produces in gpurun_out/r5set (all from ONE call on one box):
+# Produces in gpurun_out/r6set (all from ONE call on one box):
 #   bench.json + tiles.json        the default bench (two batches in flight; incl. cpu_baseline) and its tuned tile / fusion set
 #   bench_single_stream.json       the same tile set with --in-flight 1 (HIP events inside the timed blocks)
 #   in_flight_sweep.txt            scripts/two_batches.py 1 / 2 / 3
@@ -15,7 +15,7 @@
 #   bench_cfg5.json / bench_cfg2.json   BASELINE.json configs 5 and 2
 set -x
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/r5set; rm -rf $O; mkdir -p $O/pmc
+O=gpurun_out/r6set; rm -rf $O; mkdir -p $O/pmc
 SMI="rocm-smi --showclocks --showpower --showtemp --showperflevel --showmaxpower"
 $SMI > $O/smi_idle.txt 2>&1
 # the schedule of the whole set: $Y4_COLLECT_TILES (a schedule file, e.g. scripts/instep_select.py's) if given, else a fresh autotune on THIS box;
@@ -54,6 +54,15 @@ python bench.py --dtype f16 --no-cpu-baseline --no-latency --in-flight 1 > $O/be
 python scripts/halo_bench.py > $O/halo_bench_bf16.txt 2>&1
 python scripts/halo_bench.py --dtype f16 > $O/halo_bench_f16.txt 2>&1
 timeout 600 python scripts/determinism_hunt.py --sweep --iters 500 > $O/determinism_hunt.txt 2>&1
+# round 6: the halo2 tiles (conv_halo2_kernel.h) layer by layer, hot and L2-cold; what the matrix pipes sustain by operand data; the
+# race screens of the halo2 tiles (one conv under a second stream's load; the shipped schedule inside the engine)
+python scripts/halo2_bench.py > $O/halo2_bench_bf16.txt 2>&1
+python scripts/halo2_bench.py --dtype f16 --check 0 > $O/halo2_bench_f16.txt 2>&1
+python scripts/halo2_bench.py --cold 64 --check 0 > $O/halo2_bench_bf16_cold.txt 2>&1
+for f in randn zero; do echo "== fill $f"; python scripts/halo2_bench.py --check 0 --layers 0,1 --tiles 55,59,61 --fill $f 2>&1 | grep 3x3; done > $O/halo2_bench_fill.txt 2>&1
+if [ -x scratch/ubench/mfma_power ]; then for c in 256 128 64; do scratch/ubench/mfma_power $c 60; done > $O/mfma_power.txt 2>&1; fi
+for dt in bf16 f16; do for act in 1 2; do echo "== $dt act $act"; python scripts/h2_stress.py --reps 200 --dtype $dt --act $act 2>&1 | grep -v amdgpu.ids; done; done > $O/h2_stress.txt 2>&1
+for dt in bf16 f16; do python scripts/h2_det.py --dtype $dt --forwards 200 2>&1 | grep -v amdgpu.ids | tail -3; done > $O/h2_det.txt 2>&1
 # one image: the kernel timeline of a step on the shipped latency schedules (rocprofv3 --kernel-trace), bf16 and fp32
 for dt in bf16 f32; do
   rocprofv3 --kernel-trace --output-format csv -d $O/b1_$dt -- python3 bench.py --batch 1 --dtype $dt --no-cpu-baseline --no-latency --in-flight 1 --steps 40 --warmup 5 --blocks 1 > $O/b1_$dt.json 2> $O/b1_$dt.err

@@ -58,16 +58,17 @@ def _head_errors(heads, ref_heads, rows):
 # Bounds (round 5, VERDICT r4 item 4: measured + ~15 % instead of + 40 %):
 #   * the BULK figures -- mean, 99.9 % quantile, matched fraction (3 detections of 100 below the worst measured image), the 90 %
 #     quantile of the score delta -- are tight;
-#   * the TAIL figure, the largest score delta of any matched detection, is bounded by what the largest logit error allows:
-#     score = sigmoid(obj) sigmoid(cls), d score <= (|d obj| + |d cls|) / 4 <= max logit error / 2 -- a maximum over ~400 draws of a
-#     heavy tail moves by a factor of two between two fp32 summation orders of the same kernels (0.058 in round 4, 0.10 in round 5
-#     after the K order changed, every bulk figure unchanged), so it cannot be bounded tighter than the logit tail.
+#   * the TAIL figure, the largest score delta of any matched detection, has a FIXED bound since round 6 (a bound derived
+#     from the same run's worst logit error was three times what any run measured): 0.12 for bf16 against 0.058 (round 4), 0.10
+#     (round 5, after the K order changed) and 0.10 (round 6, halo2 schedule); 0.010 for fp16 against 0.008.  What the largest logit
+#     error allows -- score = sigmoid(obj) sigmoid(cls), d score <= (|d obj| + |d cls|) / 4 <= max logit error / 2 -- stays as a
+#     second, looser sanity check.
 # Identical kept indices are NOT claimed at 16-bit precision (they are, bit for bit, for the decode/NMS kernels fed the
 # oracle's heads, and within near-ties for the fp32 path: tests/test_gpu_forward.py).
 BUDGET = {
     #        mean |err|, 99.9 % quantile, min matched fraction, max score delta (tail), 90 % quantile of the score delta (bulk)
-    "bf16": (0.087, 0.40, 0.86, 0.30, 0.040),
-    "f16": (0.011, 0.050, 0.96, 0.02, 0.0042),
+    "bf16": (0.087, 0.40, 0.87, 0.12, 0.040),
+    "f16": (0.011, 0.050, 0.96, 0.010, 0.0042),
 }
 
 
