@@ -42,6 +42,7 @@ for p in (os.path.join(ROOT, "yolo-v4-tf.keras_amd"), ROOT):
         sys.path.insert(0, p)
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+SUSTAINED_TFLOPS = 1650.0      # dense bf16 / fp16 MFMA rate the chip sustains on random operands (scripts/ubench/mfma_power.hip)
 METRIC = "images/sec end-to-end predict() at 608x608 batch 32; conv MFMA %peak"
 
 
@@ -159,7 +160,7 @@ def committed_traffic(args, fused_stem, chained, staged, res_mask, tiles):
     per-layer tile ids as the profiled run (`tiles.json` next to the profile).  Counters cannot be read from inside the
     process: the figure is NOT measured by this run, `traffic_source` says where it comes from."""
     reasons = []
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", rnd, "hbm_traffic.json")
         try:
             prof = json.load(open(path))
@@ -584,6 +585,13 @@ def main():
                                              "convs / stem + convs + SPP; end_to_end_frac: all 110 convs x images/s (per GPU) / peak; timed_region_frac: the conv "
                                              "family's FLOPs / the WALL time of a step in the timed blocks (a lower bound on the family inside the "
                                              "timed region: that time also holds stem, SPP, decode, NMS and the copy of the results)",
+                         # what the matrix pipes SUSTAIN on random 16-bit operands (round 6: a register-only MFMA loop, no memory):
+                         # the power management lowers the clock to ~1.64 GHz under it -- `peak` stays the spec figure
+                         "sustained_on_random_data": ({"peak": SUSTAINED_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / SUSTAINED_TFLOPS, 4),
+                                                       "source": "scripts/ubench/mfma_power.hip, profiles/r06/mfma_power.txt: back-to-back "
+                                                                 "v_mfma_f32_32x32x16_bf16 from registers on random normal operands, all 256 CUs: "
+                                                                 "1617-1677 TFLOP/s at 1.64-1.70 GHz (zeros: 2157 at 2.17 GHz); DESIGN.md section 6a"}
+                                                      if args.dtype != "f32" else None),
                          "traffic": traffic, "traffic_unit": "HBM bytes per step (all launches of the family)",
                          "traffic_source": traffic_source,
                          "kernel": "conv kernel family (convs %d..109, %d launches/step%s)" %

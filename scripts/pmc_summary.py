@@ -29,7 +29,7 @@ for k, v in sorted(agg.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", 0) + kv
     if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
         row["hbm_read_bytes_per_step"] = 2 * v.get("FETCH_SIZE", 0.0) * 1024 / steps
         row["hbm_write_bytes_per_step"] = v.get("WRITE_SIZE", 0.0) * 1024 / steps
-        if any(x in k for x in ("conv_igemm", "csp_stage", "resblock", "conv_p8", "conv_l12")):      # the conv kernel family
+        if any(x in k for x in ("conv_igemm", "conv_halo", "csp_stage", "resblock", "conv_p8", "conv_l12")):      # the conv kernel family
             tot_f += row["hbm_read_bytes_per_step"]; tot_w += row["hbm_write_bytes_per_step"]
     rows.append(row)
 json.dump({"config": {"size": 608, "classes": 80, "batch": 32, "dtype": "bf16", "stem_fusion": True, "chain_fusion": True,

@@ -9,7 +9,7 @@
 //     v_mfma_f32_32x32x16 blocks -- the one MFMA shape a single wave issues at the pipe's full rate (32 cycles per instruction);
 //   * the INPUT is the halo tile of conv_halo_kernel.h (a band of R full image rows plus one above and below, one 64-channel chunk at
 //     a time, two buffers), staged by LDS-DMA -- but at pitch W + 2 exactly and with a swizzle that follows the PIXEL index, so the
-//     nine shifted fragment reads of a 32-pixel block are free of LDS bank conflicts (scratch/bank_sim.py; conv_halo_kernel's row & 7
+//     nine shifted fragment reads of a 32-pixel block are free of LDS bank conflicts (scripts/bank_sim.py; conv_halo_kernel's row & 7
 //     swizzle costs its kx = 1, 2 reads 1.5 extra cycles per lane group);
 //   * the WEIGHTS never touch LDS: they are kept once more in MFMA-fragment order (pack_conv_frag32: one k-step's A operand of a
 //     32-channel block = 1 KB contiguous), and each wave loads the fragments of its own channel blocks straight into registers, eight
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, OCC) void conv_halo2_kernel(const ConvK p) {
     //      columns), rows past the halo tile and pieces past the buffer get an out-of-range offset: zeros, no traffic.
     //      f(r) = ((r >> SH) - yy) & (CPR - 1): the pitch is W + 256 / RB, so the row of band pixel q = y W + x under tap (ky, kx) is
     //      q + (256 / RB) y + ky P + kx and (row mod 256 / RB, f) is a function of q + const alone: the 16 lanes of every ds_read_b128
-    //      lane group land in 16 distinct 16-byte slots of the 256-byte bank window (scratch/bank_sim.py).
+    //      lane group land in 16 distinct 16-byte slots of the 256-byte bank window (scripts/bank_sim.py).
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
     int poff[PMAX];
 #pragma unroll
