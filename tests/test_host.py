@@ -167,12 +167,12 @@ def test_resize_bilinear_against_independent_bilinear(src_hw, dst_wh):
 
 def test_shipped_schedule_is_the_profiled_tile_set():
     """The schedule that ships for the headline shape (yolo4hip/schedules/608_80_32_bf16.json, what the default bench.py
-    loads) is byte for byte the tile set the committed PMC passes were taken with (profiles/r05/tiles.json) -- that is what
-    lets bench.py quote profiles/r05/hbm_traffic.json as `roofline.traffic` -- and names one tile per conv."""
+    loads) is byte for byte the tile set the committed PMC passes were taken with (profiles/r06/tiles.json) -- that is what
+    lets bench.py quote profiles/r06/hbm_traffic.json as `roofline.traffic` -- and names one tile per conv."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     shipped = json.load(open(os.path.join(root, "yolo-v4-tf.keras_amd", "yolo4hip", "schedules", "608_80_32_bf16.json")))
-    profiled = json.load(open(os.path.join(root, "profiles", "r05", "tiles.json")))
+    profiled = json.load(open(os.path.join(root, "profiles", "r06", "tiles.json")))
     assert shipped == profiled
     assert (shipped["size"], shipped["classes"], shipped["batch"], shipped["dtype"]) == (608, 80, 32, "bf16")
     assert len(shipped["tiles"]) == 110 and shipped["in_flight"] == 2
