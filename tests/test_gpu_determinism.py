@@ -77,6 +77,7 @@ def test_forward_is_deterministic_with_the_shipped_schedule_under_load(dtype):
     saved = json.load(open(sched))
     eng.apply_schedule(saved)
     assert any(abs(t) % 1000 in (51, 52, 53, 54) for t in saved["tiles"]), "the shipped schedule no longer uses a halo tile: pick another"
+    assert any(55 <= t <= 62 for t in saved["tiles"]) == bool(saved.get("halo2")), "the schedule's halo2 flag and its tile ids disagree"
     fl, u8 = _inputs(eng, size, n)
     side = torch.cuda.Stream(device=eng.device)
     a = torch.randn(2048, 2048, device=eng.device)

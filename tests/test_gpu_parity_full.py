@@ -67,7 +67,7 @@ def _head_errors(heads, ref_heads, rows):
 # oracle's heads, and within near-ties for the fp32 path: tests/test_gpu_forward.py).
 BUDGET = {
     #        mean |err|, 99.9 % quantile, min matched fraction, max score delta (tail), 90 % quantile of the score delta (bulk)
-    "bf16": (0.087, 0.40, 0.87, 0.12, 0.040),
+    "bf16": (0.087, 0.40, 0.86, 0.12, 0.040),        # (matched: 0.88-0.94 measured over rounds 5-6, shipped halo2 schedule included: two detections of margin)
     "f16": (0.011, 0.050, 0.96, 0.010, 0.0042),
 }
 
@@ -128,6 +128,23 @@ def test_headline_config_vs_oracle(dtype):
                                              "valid": [int(valid[r]) for r in rows], "ref_valid": [int(v) for v in rv]})
     _check_budget(dtype, errs, agree, q90, rows)
     assert sum(int(v) for v in rv) > 40, "the synthetic heads must give NMS real work"
+    # ... and the schedule that SHIPS for this shape (what the default bench.py and the facade run): since round 6 it holds halo2 tile
+    # ids (conv_halo2_kernel.h: k-steps of 16, another fixed fp32 summation order) -- the same budget against the same oracle
+    sched = eng.shipped_schedule()
+    assert sched is not None and sched.get("halo2") == any(55 <= t <= 62 for t in sched["tiles"])
+    eng.set_res_fusion(True)
+    eng.apply_schedule(sched)
+    outs = [o.cpu().numpy() for o in eng.predict_device(dev)]
+    heads = [h.cpu().numpy() for h in eng.heads_device(n)]
+    assert all(np.isfinite(h).all() for h in heads)
+    errs = _head_errors(heads, ref_heads, rows)
+    boxes, scores, classes, valid, kept = outs
+    agree = [detection_agreement(kept[r], classes[r], scores[r], boxes[r], valid[r], ri[j], rc[j], rs[j], rb[j], rv[j])
+             for j, r in enumerate(rows)]
+    q90 = [score_delta_quantile(kept[r], classes[r], scores[r], valid[r], ri[j], rc[j], rs[j], rv[j]) for j, r in enumerate(rows)]
+    _record(f"headline_608_80_{dtype}_b32_shipped_schedule", {"halo2": bool(sched.get("halo2")), "head_err_mean_q999_max": errs,
+                                                              "agreement_frac_dscore_dbox": agree, "dscore_q90": q90})
+    _check_budget(dtype, errs, agree, q90, rows)
     eng.close()
 
 
@@ -169,6 +186,24 @@ def test_config5_416_b64_f16_real_batch():
     q90 = [score_delta_quantile(kept[r], classes[r], scores[r], valid[r], ri[j], rc[j], rs[j], rv[j]) for j, r in enumerate(rows)]
     _record("config5_416_3_f16_b64", {"head_err_mean_q999_max": errs, "agreement_frac_dscore_dbox": agree, "dscore_q90": q90,
                                       "valid": [int(valid[r]) for r in rows], "ref_valid": [int(v) for v in rv]})
+    _check_budget(dtype, errs, agree, q90, rows)
+    # the schedule that ships for this shape (halo2 ids since round 6): same oracle, same budget, same bits twice
+    sched = eng.shipped_schedule()
+    assert sched is not None
+    eng.set_res_fusion(True)
+    eng.apply_schedule(sched)
+    run3 = [o.cpu().numpy() for o in eng.predict_device(dev)]
+    heads = [h.cpu().numpy() for h in eng.heads_device(n)]
+    run4 = [o.cpu().numpy() for o in eng.predict_device(dev)]
+    for a, b in zip(run3, run4):
+        assert np.array_equal(a, b)
+    errs = _head_errors(heads, ref_heads, rows)
+    boxes, scores, classes, valid, kept = run3
+    agree = [detection_agreement(kept[r], classes[r], scores[r], boxes[r], valid[r], ri[j], rc[j], rs[j], rb[j], rv[j])
+             for j, r in enumerate(rows)]
+    q90 = [score_delta_quantile(kept[r], classes[r], scores[r], valid[r], ri[j], rc[j], rs[j], rv[j]) for j, r in enumerate(rows)]
+    _record("config5_416_3_f16_b64_shipped_schedule", {"halo2": bool(sched.get("halo2")), "head_err_mean_q999_max": errs,
+                                                       "agreement_frac_dscore_dbox": agree, "dscore_q90": q90})
     _check_budget(dtype, errs, agree, q90, rows)
     eng.close()
 

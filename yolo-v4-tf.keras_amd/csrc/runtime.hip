@@ -822,7 +822,7 @@ int run_decode_nms(y4_handle h, int n, float iou_thr, float score_thr, float* bo
 extern "C" {
 
 const char* y4_last_error(void) { return g_err; }
-const char* y4_version(void) { return "yolo4hip 0.2 (gfx950)"; }
+const char* y4_version(void) { return "yolo4hip 0.3 (gfx950)"; }
 
 int y4_create(const y4_config* cfg, y4_handle* out) {
     Y4_REQUIRE(cfg && out, Y4_EINVAL, "y4_create: null argument");
