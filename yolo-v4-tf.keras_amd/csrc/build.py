@@ -27,7 +27,7 @@ UNITS = ["conv_igemm_bf16", "conv_igemm_f16", "conv_p8_bf16", "conv_p8_f16", "co
 def sha(paths, extra):
     h = hashlib.sha256()
     for p in paths:
-        h.update(p.encode()); h.update(b"\0")
+        h.update(os.path.basename(p).encode()); h.update(b"\0")      # (the NAME, not the path: a pushed snapshot lives elsewhere and must not rebuild)
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(extra.encode())
