@@ -22,7 +22,14 @@
 // All loads with a register destination are inline asm with hand-counted s_waitcnt (the compiler would drain the whole queue at
 // every use beside the LDS-DMA, cdna_hip_programming.md section 5 trap (b)); the order of the K loop's statements is pinned with
 // sched_barrier.  Every wave issues exactly the same VMEM instructions per k-step (surplus halo pieces are all-lanes-out-of-range
-// dummies into a dead KB of LDS), so the counts are compile-time constants.
+// dummies into a dead KB of LDS), so the counts are compile-time constants.  Two rules keep such a kernel honest, both learnt the hard
+// way this round and both checked on the ISA by scripts/h2_audit.py (tests/test_h2_isa_audit.py): no instruction
+// may touch a register whose load has not been waited for -- which includes the registers of loads still in flight when the K loop
+// ENDS: they are dead to the compiler, so every ring register is "used" once more behind the drain --, and no LDS-DMA piece may be
+// outstanding at the barrier behind which its buffer is read.
+//
+// Template parameters beside the tile: KC = channels per staged sub-chunk (64: LDS rows of 128 B; 32: rows of 64 B at pitch W + 4, the
+// chunk's two halves one after the other -- half the LDS and half the prologue), OCC = workgroups per CU the register budget is cut for.
 //
 // K order: 64-channel chunk -> tap -> k-step of 16 channels, each v_mfma_32x32x16 summing its 16 products internally: the order of
 // conv_igemm_kernel's 32x32x16 tiles (ids 33-37) -- bit-identical to those, NOT to the 16x16x32 kernels.  The shipped schedule is
@@ -46,7 +53,6 @@ template <int I, int N, class F> __device__ __forceinline__ void h2_static_for(F
 }
 
 template <int N> __device__ __forceinline__ void h2_wait_vm_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// (a count that is a compile-time constant only after unrolling)
 __device__ __forceinline__ void h2_ds_read(u32x4& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); }
 template <int OFF> __device__ __forceinline__ void h2_wload_n(u32x4& dst, int voff, i32x4 rs) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(dst) : "v"(voff), "s"(rs), "n"(OFF));
