@@ -221,6 +221,48 @@ def test_halo2_tiles_vs_oracle(case, dtype):
     assert ran >= 2, "fewer than two halo2 tiles fit this case"
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_pack_conv_frag32_layout(dtype):
+    """y4_pack_conv_frag32 against a NumPy re-layout of the same packed matrix (include/yolo4hip.h): element e of lane l of k-step s of
+    (32-channel block b, chunk c, tap t) = packed[ch(b, l & 31)][c][t][16 s + 8 (l >> 5) + e], with MFMA row R = 8 g + 4 h + j of a block
+    <-> channel 32 b + 16 (g >> 1) + 8 h + 4 (g & 1) + j -- the layout conv_halo2_kernel's weight loads and the shared epilogue's channel
+    order both rest on.  Raw 16-bit patterns are compared: a re-layout must not touch a bit."""
+    import ctypes as C
+    import torch
+    from yolo4hip import ext
+    lib = ext.load()
+    did = ext.DTYPE_IDS[dtype]
+    cout, cin = 200, 192                                   # cout_pad 256 (rows >= 200 zero), three 64-channel chunks
+    rng = np.random.default_rng(3)
+    w = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3)) * 0.05).astype(np.float32)).to("cuda:0")
+    cpad, nbytes = C.c_int32(), C.c_size_t()
+    ext.check(lib.y4_packed_conv_bytes(did, cout, cin, 3, C.byref(cpad), C.byref(nbytes)))
+    packed = torch.zeros(nbytes.value, dtype=torch.uint8, device="cuda:0")
+    frag = torch.zeros(nbytes.value, dtype=torch.uint8, device="cuda:0")
+    ext.check(lib.y4_pack_conv_weights(did, cout, cin, 3, ext.ptr(w), ext.ptr(packed), ext.stream_ptr()))
+    ext.check(lib.y4_pack_conv_frag32(did, cout, cin, ext.ptr(packed), ext.ptr(frag), ext.stream_ptr()))
+    torch.cuda.synchronize()
+    nch = cin // 64
+    p = packed.cpu().numpy().view(np.uint16).reshape(cpad.value, nch, 9, 64)
+    f = frag.cpu().numpy().view(np.uint16).reshape(cpad.value // 32, nch, 9, 4, 64, 8)
+    R = np.arange(32)
+    g, h, j = R >> 3, (R >> 2) & 1, R & 3
+    ch_of_row = 16 * (g >> 1) + 8 * h + 4 * (g & 1) + j    # channel within the block of MFMA row R
+    want = np.empty_like(f)
+    for b in range(cpad.value // 32):
+        rows = p[32 * b + ch_of_row]                        # [R][chunk][tap][64]
+        for s in range(4):
+            for hk in range(2):
+                # lanes hk*32 + R hold input channels 16 s + 8 hk .. +7
+                want[b, :, :, s, hk * 32:(hk + 1) * 32, :] = rows[:, :, :, 16 * s + 8 * hk:16 * s + 8 * hk + 8].transpose(1, 2, 0, 3)
+    assert np.array_equal(f, want)
+    assert not f[200 // 32 + 1:].any()                      # blocks made of padding rows only
+    with pytest.raises(ext.Y4Error):
+        ext.check(lib.y4_pack_conv_frag32(ext.DTYPE_IDS["f32"], cout, cin, ext.ptr(packed), ext.ptr(frag), ext.stream_ptr()))
+    with pytest.raises(ext.Y4Error):
+        ext.check(lib.y4_pack_conv_frag32(did, cout, 96, ext.ptr(packed), ext.ptr(frag), ext.stream_ptr()))
+
+
 def test_halo2_tiles_refuse_what_they_cannot_run():
     """A halo2 tile id on a 1x1 conv, a stride-2 conv, float32, Cin % 64 != 0 -- or without the fragment-ordered weights -- is refused
     (Y4_EINVAL), never mis-run."""
