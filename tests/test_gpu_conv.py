@@ -166,6 +166,9 @@ HALO2_CASES = HALO_CASES + [
     (19, 512, 512, 3, "mish", True, (0, 0), (0, 0)),          # eight chunks, residual Add, 19 x 21 / 19 x 23 halo rows
     (24, 128, 128, 3, "linear", False, (0, 0), (0, 0)),       # a width that is no stage of the plan; the general (linear) epilogue
     (52, 128, 256, 1, "leaky", False, (64, 64), (128, 0)),    # 416 / 8; channel slices on both sides
+    (38, 128, 200, 5, "mish", False, (0, 0), (0, 56)),        # Cout = 200: the second channel tile is partly padding rows (general epilogue,
+                                                              # channel predicates); 5 images x 4 bands x 2 tiles = 40 workgroups: not a multiple of 8 XCDs
+    (19, 64, 128, 7, "leaky", True, (0, 0), (0, 0)),          # one chunk of K only (Cin = 64): prologue -> one pass of the body -> drain; 7 workgroups
 ]
 
 
